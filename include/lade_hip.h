@@ -1,0 +1,246 @@
+/*
+ * lade_hip.h -- C ABI of liblade_hip.so, the MI355X (gfx950) native hot path of lookahead decoding.
+ *
+ * Boundary contract:
+ *   - plain C: pointers + sizes, no torch / C++ types.  Device pointers are raw HBM addresses
+ *     (tensor.data_ptr()), `stream` is a hipStream_t passed as void* (torch's current stream).
+ *   - the caller owns every buffer; the library allocates nothing persistent.
+ *   - every entry point returns 0 on success or a negative LADE_E_* code and never throws;
+ *     arguments are validated on the host before any launch; lade_last_error_string() gives the
+ *     text of the last failure on the calling thread.  Asynchronous kernel faults surface at the
+ *     caller's next synchronisation, as with any HIP launch.
+ *   - all entry points are stateless and re-entrant; ordering is only through `stream`.
+ *     Everything is hipGraph-capturable (no allocation / sync inside).
+ *
+ * What each entry point replaces in the reference (paths relative to the reference repo):
+ *   lade_attn_fwd            flash_attn_lade.flash_attn_func(q,k,v,...,lookahead=[7 ints])
+ *                            lade/models/modeling_llama.py:705-713 (flash) and the eager op
+ *                            :520-541 + the dense mask of :115-207 (evaluated in-kernel here)
+ *   lade_attn_combine        (second pass of the split-KV attention; no reference counterpart)
+ *   lade_rope_kv_append      apply_rotary_pos_emb + torch.cat KV append
+ *                            lade/models/modeling_llama.py:321-346, :510-516
+ *   lade_kv_commit           lade/decoding.py:1154-1163 (greedy) / :582-590 (sample)
+ *   lade_build_inputs        lade/models/modeling_llama.py:1463-1511 (ids / position_ids assembly)
+ *   lade_argmax_rows         torch.argmax(outputs.*_logits, dim=-1)  lade/decoding.py:1021,1041,1052,1072,1102
+ *   lade_verify_greedy       lade/decoding.py:1071-1084
+ *   lade_pool_insert_window  update_token_map             lade/decoding.py:37-63
+ *   lade_pool_insert_ngrams  fill_pool_with_prompt / append_new_generated_pool  lade/decoding.py:80-127
+ *   lade_pool_lookup         lade/decoding.py:948-954
+ *   lade_window_fill_first / lade_window_fill / lade_window_roll   lade/decoding.py:1038-1066, :1119-1124
+ *   lade_greedy_post_step    the fused single-rank tail of one steady step: verify + pool insert +
+ *                            roll + next lookup + control update   lade/decoding.py:1071-1130,1165
+ *   lade_lp_pack / lade_lp_reduce_apply   the per-step lookahead-parallel exchange record
+ *                            lade/decoding.py:1023-1024, 1088-1107 (four pickled object collectives
+ *                            -> one fixed int32 all-gather issued by the host through RCCL)
+ *   lade_softmax_rows / lade_prob_gather   probs for the sampling verify  lade/decoding.py:484-489
+ *   lade_rmsnorm / lade_silu_mul  LlamaRMSNorm / SwiGLU glue around the GEMMs
+ *                            lade/models/modeling_llama.py:222-227, :360-380 ("next" row)
+ */
+#ifndef LADE_HIP_H
+#define LADE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LADE_ABI_VERSION 1
+
+/* error codes */
+#define LADE_OK 0
+#define LADE_E_ARG (-1)     /* invalid argument (null pointer, unsupported size ...) */
+#define LADE_E_DTYPE (-2)   /* unsupported dtype / head_dim for this kernel */
+#define LADE_E_LAUNCH (-3)  /* hipLaunch failed (text in lade_last_error_string) */
+#define LADE_E_LIMIT (-4)   /* a compiled-in limit exceeded (LADE_MAX_*) */
+
+/* element types of floating-point tensors */
+#define LADE_BF16 0
+#define LADE_F16 1
+#define LADE_F32 2
+
+/* compiled-in limits of the integer kernels */
+#define LADE_MAX_LEVEL 16        /* N  (n-gram size) */
+#define LADE_MAX_WINDOW 128      /* W + N - 3 */
+#define LADE_MAX_GUESS_SET 64    /* G  (candidates per key; one wave lane per slot) */
+
+/* ---- control block ------------------------------------------------------------------
+ * One int32 array in HBM carries the dynamic state of a sequence between kernels, so a steady
+ * step needs no host round trip except reading the small `record` it leaves behind.
+ * Layout (indices into int32_t ctl[LADE_CTL_WORDS]): */
+#define LADE_CTL_P 0            /* committed KV rows (= past_key_values_length of the coming step) */
+#define LADE_CTL_LST_TOKEN 1    /* lst_token: last accepted token = the next input token */
+#define LADE_CTL_LST_POS 2      /* position id of that token (= attention_mask length - 1) */
+#define LADE_CTL_N_INPUT 3      /* true input tokens fed at the head of the step (1 + guess_skip_dist) */
+#define LADE_CTL_G 4            /* candidates to verify in the coming step (0..G) */
+#define LADE_CTL_FILL_LEVEL 5   /* fill_level */
+#define LADE_CTL_MAX_HIT 6      /* results of the last step */
+#define LADE_CTL_MAX_HIT_IDX 7
+#define LADE_CTL_N_ACCEPT 8     /* max_hit + 1 */
+#define LADE_CTL_STEP 9         /* steps executed */
+#define LADE_CTL_KV_SRC 10      /* kv_commit: first source row (step_len - lguess + idx*gs) */
+#define LADE_CTL_KV_DST 11      /* kv_commit: first destination row (kvcache_len) */
+#define LADE_CTL_KV_CNT 12      /* kv_commit: rows to copy (max_hit, 0 under lookahead parallelism) */
+#define LADE_CTL_FIRST_GUESS 13
+#define LADE_CTL_HITS 16        /* hits[0..gs) */
+#define LADE_CTL_WLEN 32        /* lengths of window levels 0..N-2 */
+#define LADE_CTL_WORDS 64
+
+/* ---- attention ----------------------------------------------------------------------- */
+
+/* The lookahead mask in closed form (reference: j_make_causal_mask_multilevel,
+ * lade/models/modeling_llama.py:115-207; its flash counterpart gets the same information as
+ * lookahead=[window, level, n_guess, kv_cache, fill_offset, guess_offset, 0], :1184-1187).
+ * Token order of the T new rows: [n_input inputs | L0 | L1 .. | g*gs candidate tokens]. */
+typedef struct lade_mask_params {
+    int32_t T;            /* new tokens this step (query rows; keys P..P+T) */
+    int32_t P;            /* cached keys, visible to every row */
+    int32_t is_prefill;   /* 1: plain causal over the T new tokens (:124-130) */
+    int32_t s;            /* level_sizes[-1]                       ("window") */
+    int32_t lguess;       /* g*gs candidate rows at the tail */
+    int32_t gs;           /* tokens per candidate = N-1 */
+    int32_t level_offset; /* n_input-1 = guess_offset */
+    int32_t dist_offset;  /* 1 + level_sizes[0] - level_sizes[-1]  (fill_offset = level_offset+dist_offset) */
+} lade_mask_params;
+
+typedef struct lade_attn_args {
+    const void* q;          /* [T][H][d] rows, element stride q_row_stride between tokens */
+    const void* k_cache;    /* [Hkv][S_max][d]   keys, row-major            */
+    const void* vt_cache;   /* [Hkv][d][S_max]   values, TRANSPOSED (key index fastest) */
+    void* out;              /* [T][H][d], token stride out_row_stride */
+    float* part_o;          /* split-KV partials [n_splits][H][T][d] fp32 (n_splits>1) */
+    float* part_ml;         /* [n_splits][H][T][2]  (running max, running sum) */
+    const int32_t* dyn_P;   /* optional device int32: overrides mask.P at run time (graph replay) */
+    int64_t q_row_stride, out_row_stride; /* in elements */
+    int32_t H, Hkv, d, S_max;
+    int32_t dtype;          /* LADE_BF16 / LADE_F16 (MFMA kernel, d = 64 or 128), LADE_F32 (VALU kernel, d <= 256) */
+    int32_t n_splits;       /* >= 1 ; grid = ceil(n_rep*T/128) x H/n_rep x n_splits */
+    float scale;            /* softmax scale, 1/sqrt(d) */
+    lade_mask_params mask;
+} lade_attn_args;
+
+int lade_attn_fwd(const lade_attn_args* a, void* stream);
+/* merges the n_splits partials of lade_attn_fwd into `out` (call only when n_splits > 1) */
+int lade_attn_combine(const lade_attn_args* a, void* stream);
+/* dense 0/1 rendering of the mask predicate, [T][P+T] bytes on the device (test / debug aid) */
+int lade_mask_render(const lade_mask_params* m, uint8_t* out, void* stream);
+
+/* ---- RoPE + KV append, KV commit ----------------------------------------------------- */
+
+/* qkv: [T][(H+2*Hkv)*d] fused projection output.  Rotates q in place and writes the rotated k
+ * and v of token t into cache row P+t.  cos/sin: [max_pos][d] tables in the model dtype, built
+ * as the reference builds them (fp32 math, then cast; modeling_llama.py:248-256); the rotation
+ * reproduces the reference's per-op rounding: round(q*cos) + round(rotate_half(q)*sin), rounded.
+ * positions: device int32[T] (explicit, non-monotone position ids).  P from `dyn_P` if non-null. */
+int lade_rope_kv_append(void* qkv, const int32_t* positions, const void* cos_tab, const void* sin_tab,
+                        void* k_cache, void* vt_cache, int32_t T, int32_t P, const int32_t* dyn_P,
+                        int32_t H, int32_t Hkv, int32_t d, int32_t S_max, int32_t max_pos, int32_t dtype,
+                        void* stream);
+
+/* Copies `cnt` K/V rows src..src+cnt -> dst..dst+cnt in every layer of a [L][2] cache whose
+ * K part is [Hkv][S_max][d] and V part [Hkv][d][S_max]; layer_stride / v_offset in elements.
+ * If `ctl` is non-null, (src,dst,cnt) are read from ctl[LADE_CTL_KV_SRC..KV_CNT] on the device. */
+int lade_kv_commit(void* cache, int64_t layer_stride, int64_t v_offset, int32_t L, int32_t Hkv, int32_t d,
+                   int32_t S_max, int32_t src, int32_t dst, int32_t cnt, const int32_t* ctl, int32_t max_cnt,
+                   int32_t elem_bytes, void* stream);
+
+/* ---- integer path (all bit-exact against the reference's python logic) ---------------- */
+
+/* window: int32 [N-1][wcap] (wcap >= W+N-3), level lengths in ctl[LADE_CTL_WLEN+l].
+ * pool_tok: int32 [V][G][gs], pool_cnt: int32 [V]. */
+
+/* ids/pos <- [n_input inputs | L0[0:c1-1] | L1[c0:c1] .. L_fill[c0:c1] | candidates].  The input tokens
+ * and their positions are read from in_ids/in_pos (device); when null they come from the control block:
+ * ids = lst_token (n_input = 1) or hits[0..n_input) (re-fed accepted tokens under lookahead parallelism),
+ * positions = the n_input positions ending at ctl[LADE_CTL_LST_POS].  (c0,c1) = this rank's window columns under lookahead
+ * parallelism (lade/decoding.py:973-984), c1 < 0 = all columns.  g < 0 reads ctl[LADE_CTL_G].
+ * cand_rows >= 0 emits exactly that many candidate rows (zero tokens beyond g*gs: fixed-shape graph
+ * replay), cand_rows < 0 emits g*gs.  out_T[0] = total tokens written (may be null). */
+int lade_build_inputs(const int32_t* in_ids, const int32_t* in_pos, int32_t n_input, const int32_t* window,
+                      int32_t wcap, const int32_t* ctl, int32_t fill_level, int32_t c0, int32_t c1,
+                      const int32_t* guess, int32_t g, int32_t gs, int32_t cand_rows, int32_t* ids, int32_t* pos,
+                      int32_t* out_T, void* stream);
+
+/* one argmax per row, first index wins ties (torch.argmax semantics); logits [rows][V] with row
+ * stride `ld` elements. */
+int lade_argmax_rows(const void* logits, int64_t ld, int32_t rows, int32_t V, int32_t dtype, int32_t* out,
+                     void* stream);
+
+/* out3 = {max_hit, max_hit_idx}, hits[gs]; g may also come from ctl[LADE_CTL_G] when dyn != 0 */
+int lade_verify_greedy(const int32_t* first_guess, const int32_t* guess, const int32_t* guess_argmax, int32_t g,
+                       int32_t gs, int32_t* out2, int32_t* hits, void* stream);
+
+int lade_pool_insert_window(int32_t* pool_tok, int32_t* pool_cnt, int32_t V, int32_t G, int32_t gs,
+                            const int32_t* lst_token, const int32_t* window, int32_t wcap, const int32_t* new_results,
+                            int32_t W, int32_t N, void* stream);
+/* n sequential inserts; ngrams [n][N]: key then gs tokens */
+int lade_pool_insert_ngrams(int32_t* pool_tok, int32_t* pool_cnt, int32_t V, int32_t G, int32_t gs,
+                            const int32_t* ngrams, int32_t n, void* stream);
+/* sliding N-grams over tokens[0..len) == fill_pool_with_prompt */
+int lade_pool_fill_prompt(int32_t* pool_tok, int32_t* pool_cnt, int32_t V, int32_t G, int32_t gs,
+                          const int32_t* tokens, int32_t len, void* stream);
+/* guess_out [G*gs], g_out[0] = number of tuples stored under *key (0 if none) */
+int lade_pool_lookup(const int32_t* pool_tok, const int32_t* pool_cnt, int32_t V, int32_t G, int32_t gs,
+                     const int32_t* key, int32_t* guess_out, int32_t* g_out, void* stream);
+
+int lade_window_fill_first(int32_t* window, int32_t wcap, int32_t* ctl, const int32_t* inp_argmax, int32_t n,
+                           void* stream);
+int lade_window_fill(int32_t* window, int32_t wcap, int32_t* ctl, int32_t fill_level, const int32_t* inp_argmax,
+                     int32_t n, void* stream);
+int lade_window_roll(int32_t* window, int32_t wcap, int32_t* ctl, const int32_t* new_results, int32_t W, int32_t N,
+                     void* stream);
+
+/* Fused tail of one single-rank greedy step.  am = argmax rows in the order
+ * [out row | n_inp inp rows | cand_rows guess rows].  phase 0 = prefill step (L1 <- inp rows),
+ * 1 = window-fill step, 2 = steady step.  Does: verify (g = ctl[G], phase 2) -> pool insert (W n-grams)
+ * -> window fill / roll -> EOS scan + POOL_FROM_PROMPT appends (`tail` = [len, last <=N tokens of the
+ * reference's all_old_tokens]) -> lookup of the next step's candidates into `guess` / ctl[G] -> ctl update
+ * (P, lst_token, lst_pos, kv-commit triple, hits, step).
+ * record = {max_hit, n_accept, finished_by_eos, g_next, P_next, max_hit_idx, first_guess, -, hits[gs]}.
+ * eos < 0 disables the EOS scan; the scan follows lade/decoding.py:1167-1177. */
+int lade_greedy_post_step(int32_t* ctl, int32_t* window, int32_t wcap, int32_t* pool_tok, int32_t* pool_cnt,
+                          int32_t V, int32_t W, int32_t N, int32_t G, const int32_t* am, int32_t n_inp,
+                          int32_t* guess, int32_t T_step, int32_t cand_rows, int32_t phase, int32_t pool_from_prompt,
+                          int32_t* tail, int32_t eos, int32_t* record, void* stream);
+
+/* lookahead parallelism: rank-local verify + record packing, then (after the host's RCCL all-gather of
+ * rec_words int32 per rank) the deterministic reduction every rank applies (same phases as above).
+ * rec = [first_guess, max_hit, max_hit_idx, n_inp, hits[gs], new tokens[split]]; rec_words >= 4+gs+split.
+ * scratch: int32[R*split]. */
+int lade_lp_pack(const int32_t* am_out, const int32_t* am_inp, int32_t n_inp, const int32_t* guess,
+                 const int32_t* am_guess, int32_t g_local, int32_t gs, int32_t split, int32_t* rec,
+                 int32_t rec_words, void* stream);
+int lade_lp_reduce_apply(const int32_t* all_rec, int32_t R, int32_t rec_words, int32_t split, int32_t* ctl,
+                         int32_t* window, int32_t wcap, int32_t* pool_tok, int32_t* pool_cnt, int32_t V, int32_t W,
+                         int32_t N, int32_t G, int32_t phase, int32_t* guess_all, int32_t* scratch, int32_t* record,
+                         void* stream);
+
+/* ---- sampling helpers ------------------------------------------------------------------ */
+/* probs[r][:] = softmax(logits[r][:] / temperature) in fp32 */
+int lade_softmax_rows(const void* logits, int64_t ld, int32_t rows, int32_t V, int32_t dtype, float temperature,
+                      float* probs, void* stream);
+
+/* ---- glue around the GEMMs -------------------------------------------------------------- */
+/* y = weight * (x * rsqrt(mean(x^2) + eps)) with the reference's rounding (fp32 norm, cast, then * weight) */
+int lade_rmsnorm(const void* x, const void* weight, void* y, int32_t rows, int32_t hidden, float eps, int32_t dtype,
+                 void* stream);
+/* y = x + r (residual add) fused with the norm of the sum: x <- x + r ; y = rmsnorm(x) */
+int lade_add_rmsnorm(void* x, const void* r, const void* weight, void* y, int32_t rows, int32_t hidden, float eps,
+                     int32_t dtype, void* stream);
+/* out[r][i] = silu(gu[r][i]) * gu[r][inter + i]   (gate and up projections fused in one GEMM) */
+int lade_silu_mul(const void* gu, void* out, int32_t rows, int32_t inter, int32_t dtype, void* stream);
+/* dst[r][:] = src[idx[r]][:]  (row gather: embedding lookup, logits-row selection) */
+int lade_gather_rows(const void* src, const int32_t* idx, void* dst, int32_t rows, int32_t width, int32_t elem_bytes,
+                     int32_t src_rows, void* stream);
+
+/* ---- misc ------------------------------------------------------------------------------- */
+int lade_version(void);
+const char* lade_last_error_string(void);
+/* kernel timing helper for bench.py: runs `reps` launches of lade_attn_fwd (+combine) on `stream`
+ * bracketed by hipEvents and returns the mean duration of one launch pair in microseconds. */
+int lade_time_attn(const lade_attn_args* a, int32_t reps, float* mean_us, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LADE_HIP_H */

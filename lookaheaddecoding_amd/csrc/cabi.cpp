@@ -1,0 +1,59 @@
+// liblade_hip.so: error channel, version and the kernel-timing helper used by bench.py.
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.hpp"
+
+namespace lade {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return LADE_E_LAUNCH;
+    }
+    return LADE_OK;
+}
+
+}  // namespace lade
+
+extern "C" int lade_version(void) { return LADE_ABI_VERSION; }
+extern "C" const char* lade_last_error_string(void) { return lade::g_err; }
+
+// Mean duration (us) of `reps` back-to-back launches of the attention kernel pair on `stream`,
+// measured with hipEvents recorded on that same stream.
+extern "C" int lade_time_attn(const lade_attn_args* a, int32_t reps, float* mean_us, void* stream) {
+    LADE_REQUIRE(a && mean_us && reps > 0, LADE_E_ARG, "lade_time_attn: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        lade::set_error("lade_time_attn: hipEventCreate failed");
+        return LADE_E_LAUNCH;
+    }
+    int rc = lade_attn_fwd(a, stream);            // warm-up, also validates
+    if (rc == 0 && a->n_splits > 1) rc = lade_attn_combine(a, stream);
+    if (rc == 0) {
+        (void)hipEventRecord(e0, st);
+        for (int i = 0; i < reps && rc == 0; ++i) {
+            rc = lade_attn_fwd(a, stream);
+            if (rc == 0 && a->n_splits > 1) rc = lade_attn_combine(a, stream);
+        }
+        (void)hipEventRecord(e1, st);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        *mean_us = ms * 1000.f / (float)reps;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}

@@ -1,0 +1,74 @@
+// Shared host/device helpers of liblade_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/lade_hip.h"
+
+namespace lade {
+
+// ---- host: error reporting (thread local, read through lade_last_error_string) --------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define LADE_REQUIRE(cond, code, ...)      \
+    do {                                   \
+        if (!(cond)) {                     \
+            lade::set_error(__VA_ARGS__);  \
+            return (code);                 \
+        }                                  \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- device: 16-bit float storage <-> fp32 ---------------------------------------------
+struct BF16 {};  // tag types: storage is uint16_t
+struct F16 {};
+struct F32 {};  // 4-byte storage
+
+template <typename T>
+__device__ __forceinline__ float to_f32(uint16_t v);
+template <>
+__device__ __forceinline__ float to_f32<BF16>(uint16_t v) {
+    return __uint_as_float(((uint32_t)v) << 16);
+}
+template <>
+__device__ __forceinline__ float to_f32<F16>(uint16_t v) {
+    _Float16 h;
+    __builtin_memcpy(&h, &v, 2);
+    return (float)h;
+}
+
+template <typename T>
+__device__ __forceinline__ uint16_t from_f32(float f);
+template <>
+__device__ __forceinline__ uint16_t from_f32<BF16>(float f) {  // round to nearest even, NaN kept quiet
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+template <>
+__device__ __forceinline__ uint16_t from_f32<F16>(float f) {
+    _Float16 h = (_Float16)f;  // v_cvt_f16_f32, RTE
+    uint16_t v;
+    __builtin_memcpy(&v, &h, 2);
+    return v;
+}
+
+// two fp32 -> packed pair of 16-bit floats (lo in bits 0..15)
+template <typename T>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi);
+template <>
+__device__ __forceinline__ uint32_t pack2<BF16>(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+template <>
+__device__ __forceinline__ uint32_t pack2<F16>(float lo, float hi) {
+    return (uint32_t)from_f32<F16>(lo) | ((uint32_t)from_f32<F16>(hi) << 16);
+}
+
+}  // namespace lade

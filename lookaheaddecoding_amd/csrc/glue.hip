@@ -1,0 +1,162 @@
+// Elementwise / row kernels around the GEMMs of one model step: RMSNorm (+ residual add), SwiGLU
+// gate, row gather (embedding lookup, logits-row selection) and the fp32 row softmax used by the
+// sampling verify.  Reference: LlamaRMSNorm / LlamaMLP (lade/models/modeling_llama.py:222-227,
+// :360-380), lade/decoding.py:484-489.  All HBM-streaming: 16-byte accesses, one pass.
+#include "common.hpp"
+
+namespace lade {
+
+template <typename T> struct St;
+template <> struct St<BF16> { typedef uint16_t S; };
+template <> struct St<F16> { typedef uint16_t S; };
+template <> struct St<F32> { typedef float S; };
+template <typename T> __device__ __forceinline__ float ldf(const typename St<T>::S* p, size_t i);
+template <> __device__ __forceinline__ float ldf<BF16>(const uint16_t* p, size_t i) { return to_f32<BF16>(p[i]); }
+template <> __device__ __forceinline__ float ldf<F16>(const uint16_t* p, size_t i) { return to_f32<F16>(p[i]); }
+template <> __device__ __forceinline__ float ldf<F32>(const float* p, size_t i) { return p[i]; }
+template <typename T> __device__ __forceinline__ typename St<T>::S stf(float f);
+template <> __device__ __forceinline__ uint16_t stf<BF16>(float f) { return from_f32<BF16>(f); }
+template <> __device__ __forceinline__ uint16_t stf<F16>(float f) { return from_f32<F16>(f); }
+template <> __device__ __forceinline__ float stf<F32>(float f) { return f; }
+
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 0) sm[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += sm[i];
+    __syncthreads();
+    return t;
+}
+__device__ __forceinline__ float block_max(float v, float* sm) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 0) sm[w] = v;
+    __syncthreads();
+    float t = -INFINITY;
+    for (int i = 0; i < nw; ++i) t = fmaxf(t, sm[i]);
+    __syncthreads();
+    return t;
+}
+
+// y = w * cast(x_f32 * rsqrt(mean(x^2)+eps));  ADD: x <- cast(x + r) first (residual), norm of the sum
+template <typename T, bool ADD>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(typename St<T>::S* x, const typename St<T>::S* r, const typename St<T>::S* w,
+                                                      typename St<T>::S* y, int hidden, float eps) {
+    __shared__ float sm[8];
+    const size_t base = (size_t)blockIdx.x * hidden;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < hidden; i += blockDim.x) {
+        float v = ldf<T>(x, base + i);
+        if (ADD) {
+            v = ldf<T>(&x[0], base + i) + ldf<T>(r, base + i);
+            const typename St<T>::S sv = stf<T>(v);
+            x[base + i] = sv;
+            v = ldf<T>(&sv, 0);
+        }
+        ss += v * v;
+    }
+    const float var = block_sum(ss, sm) / (float)hidden;
+    const float inv = rsqrtf(var + eps);
+    for (int i = threadIdx.x; i < hidden; i += blockDim.x) {
+        const float v = ldf<T>(x, base + i);
+        const typename St<T>::S n = stf<T>(v * inv);             // hidden_states.to(input_dtype)
+        y[base + i] = stf<T>(ldf<T>(w, i) * ldf<T>(&n, 0));        // weight * ...
+    }
+}
+
+// out[r][i] = silu(gu[r][i]) * gu[r][inter+i], rounded like torch: act(gate) -> dtype, then * up -> dtype
+template <typename T>
+__global__ __launch_bounds__(256) void silu_mul_kernel(const typename St<T>::S* gu, typename St<T>::S* out, int inter) {
+    const size_t rb = (size_t)blockIdx.y * 2 * inter;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= inter) return;
+    const float g = ldf<T>(gu, rb + i), u = ldf<T>(gu, rb + inter + i);
+    const typename St<T>::S a = stf<T>(g / (1.f + __expf(-g)));
+    out[(size_t)blockIdx.y * inter + i] = stf<T>(ldf<T>(&a, 0) * u);
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const unsigned char* src, const int32_t* idx, unsigned char* dst, int row_bytes, int src_rows) {
+    int r = idx[blockIdx.x];
+    r = r < 0 ? 0 : (r >= src_rows ? src_rows - 1 : r);
+    const unsigned char* s = src + (size_t)r * row_bytes;
+    unsigned char* d = dst + (size_t)blockIdx.x * row_bytes;
+    if ((row_bytes & 15) == 0) {
+        for (int i = threadIdx.x * 16; i < row_bytes; i += blockDim.x * 16) *reinterpret_cast<uint4*>(d + i) = *reinterpret_cast<const uint4*>(s + i);
+    } else {
+        for (int i = threadIdx.x; i < row_bytes; i += blockDim.x) d[i] = s[i];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const typename St<T>::S* logits, int64_t ld, int V, float inv_temp, float* probs) {
+    __shared__ float sm[8];
+    const size_t base = (size_t)blockIdx.x * ld;
+    float* out = probs + (size_t)blockIdx.x * V;
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) mx = fmaxf(mx, ldf<T>(logits, base + i) * inv_temp);
+    mx = block_max(mx, sm);
+    float s = 0.f;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) {
+        const float e = expf(ldf<T>(logits, base + i) * inv_temp - mx);
+        out[i] = e;
+        s += e;
+    }
+    s = block_sum(s, sm);
+    const float inv = 1.f / s;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) out[i] *= inv;
+}
+
+}  // namespace lade
+
+using namespace lade;
+
+#define DISPATCH_DTYPE(dtype, CALL)                                   \
+    switch (dtype) {                                                  \
+        case LADE_BF16: { typedef BF16 TT; CALL; } break;             \
+        case LADE_F16: { typedef F16 TT; CALL; } break;               \
+        case LADE_F32: { typedef F32 TT; CALL; } break;               \
+        default: LADE_REQUIRE(false, LADE_E_DTYPE, "unsupported dtype %d", dtype); \
+    }
+
+extern "C" int lade_rmsnorm(const void* x, const void* weight, void* y, int32_t rows, int32_t hidden, float eps, int32_t dtype, void* stream) {
+    LADE_REQUIRE(x && weight && y && rows >= 0 && hidden > 0, LADE_E_ARG, "lade_rmsnorm: rows=%d hidden=%d", rows, hidden);
+    if (rows == 0) return LADE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((rmsnorm_kernel<TT, false>), dim3(rows), dim3(256), 0, st, (St<TT>::S*)x, (const St<TT>::S*)nullptr,
+                                             (const St<TT>::S*)weight, (St<TT>::S*)y, hidden, eps));
+    return check_launch("lade_rmsnorm");
+}
+
+extern "C" int lade_add_rmsnorm(void* x, const void* r, const void* weight, void* y, int32_t rows, int32_t hidden, float eps, int32_t dtype, void* stream) {
+    LADE_REQUIRE(x && r && weight && y && rows >= 0 && hidden > 0, LADE_E_ARG, "lade_add_rmsnorm: rows=%d hidden=%d", rows, hidden);
+    if (rows == 0) return LADE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((rmsnorm_kernel<TT, true>), dim3(rows), dim3(256), 0, st, (St<TT>::S*)x, (const St<TT>::S*)r,
+                                             (const St<TT>::S*)weight, (St<TT>::S*)y, hidden, eps));
+    return check_launch("lade_add_rmsnorm");
+}
+
+extern "C" int lade_silu_mul(const void* gu, void* out, int32_t rows, int32_t inter, int32_t dtype, void* stream) {
+    LADE_REQUIRE(gu && out && rows >= 0 && inter > 0, LADE_E_ARG, "lade_silu_mul: rows=%d inter=%d", rows, inter);
+    if (rows == 0) return LADE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(silu_mul_kernel<TT>, dim3(cdiv(inter, 256), rows), dim3(256), 0, st, (const St<TT>::S*)gu, (St<TT>::S*)out, inter));
+    return check_launch("lade_silu_mul");
+}
+
+extern "C" int lade_gather_rows(const void* src, const int32_t* idx, void* dst, int32_t rows, int32_t width, int32_t elem_bytes, int32_t src_rows, void* stream) {
+    LADE_REQUIRE(src && idx && dst && rows >= 0 && width > 0 && elem_bytes > 0 && src_rows > 0, LADE_E_ARG, "lade_gather_rows: rows=%d width=%d", rows, width);
+    if (rows == 0) return LADE_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)src, idx, (unsigned char*)dst, width * elem_bytes, src_rows);
+    return check_launch("lade_gather_rows");
+}
+
+extern "C" int lade_softmax_rows(const void* logits, int64_t ld, int32_t rows, int32_t V, int32_t dtype, float temperature, float* probs, void* stream) {
+    LADE_REQUIRE(logits && probs && rows >= 0 && V > 0 && ld >= V && temperature > 0.f, LADE_E_ARG, "lade_softmax_rows: rows=%d V=%d T=%f", rows, V, temperature);
+    if (rows == 0) return LADE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(softmax_rows_kernel<TT>, dim3(rows), dim3(256), 0, st, (const St<TT>::S*)logits, ld, V, 1.f / temperature, probs));
+    return check_launch("lade_softmax_rows");
+}

@@ -1,0 +1,149 @@
+// RoPE with gathered positions fused with the in-place KV append, and the post-accept KV commit.
+//
+// Reference: apply_rotary_pos_emb + torch.cat (lade/models/modeling_llama.py:321-346, :510-516) and
+// the commit loop of lade/decoding.py:1154-1163.  The reference re-copies the whole cache with
+// torch.cat in every layer of every step; here the cache is preallocated ([Hkv][S_max][d] keys,
+// [Hkv][d][S_max] transposed values) and only the T new rows are written.
+#include "common.hpp"
+
+namespace lade {
+
+// storage-type helpers: 16-bit types round after every elementwise op exactly like torch does
+// (fp32 math, one rounding per op); fp32 uses separately rounded mul / add (no contraction).
+template <typename T> struct Elem;
+template <> struct Elem<BF16> { typedef uint16_t S; __device__ static float ld(S v) { return to_f32<BF16>(v); } __device__ static S st(float f) { return from_f32<BF16>(f); } };
+template <> struct Elem<F16> { typedef uint16_t S; __device__ static float ld(S v) { return to_f32<F16>(v); } __device__ static S st(float f) { return from_f32<F16>(f); } };
+template <> struct Elem<F32> { typedef float S; __device__ static float ld(S v) { return v; } __device__ static S st(float f) { return f; } };
+
+template <typename T>
+__device__ __forceinline__ float rnd(float f) { return Elem<T>::ld(Elem<T>::st(f)); }
+
+// grid: (T tokens); threads loop over (head, i < d/2).  q rotated in place, rotated k -> cache.
+template <typename T>
+__global__ __launch_bounds__(256) void rope_append_kernel(typename Elem<T>::S* qkv, const int32_t* positions,
+                                                          const typename Elem<T>::S* cos_tab,
+                                                          const typename Elem<T>::S* sin_tab,
+                                                          typename Elem<T>::S* k_cache, int P, const int32_t* dyn_P,
+                                                          int H, int Hkv, int d, int S_max, int max_pos) {
+    typedef typename Elem<T>::S S;
+    const int t = blockIdx.x;
+    if (dyn_P) P = *dyn_P;
+    int pos = positions[t];
+    pos = pos < 0 ? 0 : (pos >= max_pos ? max_pos - 1 : pos);
+    const S* c = cos_tab + (size_t)pos * d;
+    const S* s = sin_tab + (size_t)pos * d;
+    const int half = d >> 1;
+    S* row = qkv + (size_t)t * (H + 2 * Hkv) * d;
+    const int n_pairs = (H + Hkv) * half;
+    for (int idx = threadIdx.x; idx < n_pairs; idx += blockDim.x) {
+        const int h = idx / half, i = idx - h * half;
+        S* x = row + (size_t)h * d;
+        const float x1 = Elem<T>::ld(x[i]), x2 = Elem<T>::ld(x[i + half]);
+        const float c1 = Elem<T>::ld(c[i]), c2 = Elem<T>::ld(c[i + half]);
+        const float s1 = Elem<T>::ld(s[i]), s2 = Elem<T>::ld(s[i + half]);
+        // q*cos + rotate_half(q)*sin, rotate_half = cat(-x2, x1)
+        const float o1 = rnd<T>(__fadd_rn(rnd<T>(__fmul_rn(x1, c1)), rnd<T>(__fmul_rn(-x2, s1))));
+        const float o2 = rnd<T>(__fadd_rn(rnd<T>(__fmul_rn(x2, c2)), rnd<T>(__fmul_rn(x1, s2))));
+        if (h < H) {
+            x[i] = Elem<T>::st(o1);
+            x[i + half] = Elem<T>::st(o2);
+        } else {
+            S* kr = k_cache + ((size_t)(h - H) * S_max + P + t) * d;
+            kr[i] = Elem<T>::st(o1);
+            kr[i + half] = Elem<T>::st(o2);
+        }
+    }
+}
+
+// grid: (Hkv, ceil(T/64)); transposes 64 tokens x d of V through LDS so the writes run along keys.
+template <typename T>
+__global__ __launch_bounds__(256) void v_append_kernel(const typename Elem<T>::S* qkv, typename Elem<T>::S* vt_cache,
+                                                       int T_, int P, const int32_t* dyn_P, int H, int Hkv, int d,
+                                                       int S_max) {
+    typedef typename Elem<T>::S S;
+    extern __shared__ unsigned char sm_raw[];
+    S* sm = reinterpret_cast<S*>(sm_raw);          // [64][d+1]
+    if (dyn_P) P = *dyn_P;
+    const int kvh = blockIdx.x, t0 = blockIdx.y * 64;
+    const int nt = min(64, T_ - t0);
+    const int ld = d + 1;
+    for (int idx = threadIdx.x; idx < nt * d; idx += blockDim.x) {
+        const int tt = idx / d, dd = idx - tt * d;
+        sm[tt * ld + dd] = qkv[(size_t)(t0 + tt) * (H + 2 * Hkv) * d + (size_t)(H + Hkv + kvh) * d + dd];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * d; idx += blockDim.x) {
+        const int dd = idx >> 6, tt = idx & 63;
+        if (tt < nt) vt_cache[((size_t)kvh * d + dd) * S_max + P + t0 + tt] = sm[tt * ld + dd];
+    }
+}
+
+// grid (L, Hkv): copy cnt rows src.. -> dst.. of K ([S_max][d]) and V^T ([d][S_max])
+template <typename S>
+__global__ __launch_bounds__(256) void kv_commit_kernel(S* cache, int64_t layer_stride, int64_t v_offset, int Hkv, int d,
+                                                        int S_max, int src, int dst, int cnt, const int32_t* ctl) {
+    if (ctl) { src = ctl[LADE_CTL_KV_SRC]; dst = ctl[LADE_CTL_KV_DST]; cnt = ctl[LADE_CTL_KV_CNT]; }
+    if (cnt <= 0) return;
+    S* kc = cache + (size_t)blockIdx.x * layer_stride + (size_t)blockIdx.y * S_max * d;
+    S* vc = cache + (size_t)blockIdx.x * layer_stride + v_offset + (size_t)blockIdx.y * d * S_max;
+    for (int idx = threadIdx.x; idx < cnt * d; idx += blockDim.x) {
+        const int j = idx / d, dd = idx - j * d;
+        kc[(size_t)(dst + j) * d + dd] = kc[(size_t)(src + j) * d + dd];
+    }
+    for (int idx = threadIdx.x; idx < cnt * d; idx += blockDim.x) {
+        const int dd = idx / cnt, j = idx - dd * cnt;
+        vc[(size_t)dd * S_max + dst + j] = vc[(size_t)dd * S_max + src + j];
+    }
+}
+
+template <typename T>
+static int launch_rope(void* qkv, const int32_t* positions, const void* cos_tab, const void* sin_tab, void* k_cache,
+                       void* vt_cache, int T_, int P, const int32_t* dyn_P, int H, int Hkv, int d, int S_max, int max_pos,
+                       hipStream_t st) {
+    typedef typename Elem<T>::S S;
+    hipLaunchKernelGGL(rope_append_kernel<T>, dim3(T_), dim3(256), 0, st, (S*)qkv, positions, (const S*)cos_tab,
+                       (const S*)sin_tab, (S*)k_cache, P, dyn_P, H, Hkv, d, S_max, max_pos);
+    int rc = check_launch("lade_rope_kv_append(rope)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(v_append_kernel<T>, dim3(Hkv, cdiv(T_, 64)), dim3(256), 64 * (d + 1) * sizeof(S), st, (const S*)qkv,
+                       (S*)vt_cache, T_, P, dyn_P, H, Hkv, d, S_max);
+    return check_launch("lade_rope_kv_append(v)");
+}
+
+}  // namespace lade
+
+using namespace lade;
+
+extern "C" int lade_rope_kv_append(void* qkv, const int32_t* positions, const void* cos_tab, const void* sin_tab,
+                                   void* k_cache, void* vt_cache, int32_t T, int32_t P, const int32_t* dyn_P, int32_t H,
+                                   int32_t Hkv, int32_t d, int32_t S_max, int32_t max_pos, int32_t dtype, void* stream) {
+    LADE_REQUIRE(qkv && positions && cos_tab && sin_tab && k_cache && vt_cache, LADE_E_ARG, "lade_rope_kv_append: null pointer");
+    LADE_REQUIRE(T > 0 && P >= 0 && P + T <= S_max && H > 0 && Hkv > 0 && d > 0 && d % 2 == 0 && d <= 256 && max_pos > 0,
+                 LADE_E_ARG, "lade_rope_kv_append: T=%d P=%d S_max=%d H=%d Hkv=%d d=%d", T, P, S_max, H, Hkv, d);
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case LADE_BF16: return launch_rope<BF16>(qkv, positions, cos_tab, sin_tab, k_cache, vt_cache, T, P, dyn_P, H, Hkv, d, S_max, max_pos, st);
+        case LADE_F16: return launch_rope<F16>(qkv, positions, cos_tab, sin_tab, k_cache, vt_cache, T, P, dyn_P, H, Hkv, d, S_max, max_pos, st);
+        case LADE_F32: return launch_rope<F32>(qkv, positions, cos_tab, sin_tab, k_cache, vt_cache, T, P, dyn_P, H, Hkv, d, S_max, max_pos, st);
+    }
+    LADE_REQUIRE(false, LADE_E_DTYPE, "lade_rope_kv_append: dtype=%d", dtype);
+}
+
+extern "C" int lade_kv_commit(void* cache, int64_t layer_stride, int64_t v_offset, int32_t L, int32_t Hkv, int32_t d,
+                              int32_t S_max, int32_t src, int32_t dst, int32_t cnt, const int32_t* ctl, int32_t max_cnt,
+                              int32_t elem_bytes, void* stream) {
+    LADE_REQUIRE(cache && L > 0 && Hkv > 0 && d > 0 && S_max > 0, LADE_E_ARG, "lade_kv_commit: bad args");
+    LADE_REQUIRE(elem_bytes == 2 || elem_bytes == 4, LADE_E_DTYPE, "lade_kv_commit: elem_bytes=%d", elem_bytes);
+    if (!ctl) {
+        LADE_REQUIRE(cnt >= 0 && src >= 0 && dst >= 0 && src + cnt <= S_max && dst + cnt <= S_max && (cnt == 0 || src >= dst + cnt || dst >= src + cnt),
+                     LADE_E_ARG, "lade_kv_commit: src=%d dst=%d cnt=%d S_max=%d", src, dst, cnt, S_max);
+        if (cnt == 0) return LADE_OK;
+    }
+    (void)max_cnt;
+    hipStream_t st = (hipStream_t)stream;
+    if (elem_bytes == 2)
+        hipLaunchKernelGGL(kv_commit_kernel<uint16_t>, dim3(L, Hkv), dim3(256), 0, st, (uint16_t*)cache, layer_stride, v_offset, Hkv, d, S_max, src, dst, cnt, ctl);
+    else
+        hipLaunchKernelGGL(kv_commit_kernel<uint32_t>, dim3(L, Hkv), dim3(256), 0, st, (uint32_t*)cache, layer_stride, v_offset, Hkv, d, S_max, src, dst, cnt, ctl);
+    return check_launch("lade_kv_commit");
+}

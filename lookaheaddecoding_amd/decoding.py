@@ -1,0 +1,181 @@
+"""Lookahead decode loops on the MI355X step engine.
+
+Mirrors the reference's `lade/decoding.py`: `greedy_search_proxy` / `sample_proxy` (:15-34),
+`jacobi_greedy_search_multilevel` (:697-1259) and `jacobi_sample_multilevel` (:137-692), with the
+same module globals `CONFIG_MAP` / `FUNC_MAP` (:11-12).  What differs is where the work happens:
+the window, the n-gram pool, verification, the window roll and the KV commit live on the GPU
+(`liblade_hip.so`); the host loop only launches a step, reads back one small record
+(`max_hit`, accepted tokens, next candidate count) and applies the stopping criteria.
+"""
+from __future__ import annotations
+
+import os
+import random
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import cabi, ops
+from .cabi import (CTL_FILL_LEVEL, CTL_G, CTL_HITS, CTL_LST_POS, CTL_LST_TOKEN, CTL_N_INPUT, CTL_P, CTL_WLEN, CTL_WORDS,
+                   REC_WORDS, call, ptr)
+from .engine import StepEngine
+from .ops import StepMask
+
+FUNC_MAP: dict = {}
+CONFIG_MAP: dict = {}
+COLOR_PRINT = int(os.environ.get("COLOR_PRINT", 0))
+
+
+@dataclass
+class GenOut:
+    tokens: List[int]            # prompt + generated, trimmed to max_length like the reference (:1221-1229)
+    steps: int
+    generated: int
+    trace: List[dict] = field(default_factory=list)
+
+
+class LadeState:
+    """Device-resident integer state of one sequence: window [N-1][wcap], pool [V][G][gs], control block."""
+
+    def __init__(self, V: int, W: int, N: int, G: int, device, max_T: int):
+        if not (3 <= N <= cabi.MAX_LEVEL):
+            raise cabi.LadeHipError(f"LEVEL={N} unsupported (3..{cabi.MAX_LEVEL}; the reference itself needs LEVEL >= 3)")
+        if not (1 <= G <= cabi.MAX_GUESS_SET):
+            raise cabi.LadeHipError(f"GUESS_SET_SIZE={G} unsupported (1..{cabi.MAX_GUESS_SET})")
+        if W < 1 or W + N - 3 > cabi.MAX_WINDOW:
+            raise cabi.LadeHipError(f"WINDOW_SIZE={W} unsupported")
+        self.V, self.W, self.N, self.G, self.gs = V, W, N, G, N - 1
+        self.wcap = W + N - 3
+        i32 = dict(dtype=torch.int32, device=device)
+        self.window = torch.zeros(N - 1, self.wcap, **i32)
+        self.ctl = torch.zeros(CTL_WORDS, **i32)
+        self.pool_tok = torch.zeros(V, G, self.gs, **i32)
+        self.pool_cnt = torch.zeros(V, **i32)
+        self.guess = torch.zeros(G * self.gs, **i32)
+        self.tail = torch.zeros(N + 2, **i32)
+        self.ids = torch.zeros(max_T, **i32)
+        self.pos = torch.zeros(max_T, **i32)
+        self.sel = torch.zeros(1 + self.wcap + G * self.gs, **i32)
+        self.am = torch.zeros(1 + self.wcap + G * self.gs, **i32)
+        self.record = torch.zeros(REC_WORDS, **i32)
+        self.record_host = torch.zeros(REC_WORDS, dtype=torch.int32).pin_memory()
+        self.device = device
+
+    def reset(self, window0: Sequence[int], n_prompt: int, prompt_tail: Sequence[int]) -> None:
+        N = self.N
+        ctl = [0] * CTL_WORDS
+        ctl[CTL_N_INPUT] = n_prompt
+        ctl[CTL_LST_POS] = n_prompt - 1
+        ctl[CTL_WLEN] = len(window0)
+        self.ctl.copy_(torch.tensor(ctl, dtype=torch.int32))
+        self.window.zero_()
+        self.window[0, :len(window0)] = torch.tensor(list(window0), dtype=torch.int32)
+        self.pool_cnt.zero_()
+        t = list(prompt_tail)[-N:]
+        self.tail.copy_(torch.tensor([len(t)] + t + [0] * (N + 1 - len(t)), dtype=torch.int32))
+
+    def read_record(self) -> List[int]:
+        self.record_host.copy_(self.record, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return self.record_host.tolist()
+
+
+class LookaheadDecoder:
+    """Greedy / sampling lookahead decoding of one sequence on a `StepEngine`."""
+
+    def __init__(self, engine: StepEngine, W: int, N: int, G: int, pool_from_prompt: bool = False, lp=None):
+        self.e = engine
+        self.W, self.N, self.G, self.gs = W, N, G, N - 1
+        self.pool_from_prompt = bool(pool_from_prompt)
+        self.lp = lp                      # lookahead-parallel context (parallel.LPContext) or None
+        self.st = LadeState(engine.V, W, N, G, engine.device, engine.max_T)
+        if self.max_step_tokens() > engine.max_T:
+            raise cabi.LadeHipError(f"W={W} N={N} G={G} needs {self.max_step_tokens()} tokens per step > engine.max_T={engine.max_T}")
+
+    def max_step_tokens(self) -> int:
+        return self.gs + (self.N - 1) * self.W + self.G * self.gs
+
+    # ---- helpers --------------------------------------------------------------------------------
+    def _level_sizes(self, fill_level: int) -> List[int]:
+        """Lengths of window levels 0..fill_level before the step with that fill level
+        (init W+N-3 at lade/decoding.py:902; each fill step trims one: :1040, :1050-1051)."""
+        W, N = self.W, self.N
+        if fill_level == 0:
+            return [W + N - 3]
+        if fill_level >= N - 2:
+            return [W - 1] + [W] * (N - 2)
+        return [W + N - 3 - fill_level] + [W + N - 2 - fill_level] * fill_level
+
+    def _set_sel(self, rows: List[int]) -> int:
+        self.st.sel[:len(rows)].copy_(torch.tensor(rows, dtype=torch.int32), non_blocking=True)
+        return len(rows)
+
+    @torch.no_grad()
+    def greedy(self, prompt: Sequence[int], max_length: int, eos_token_id: Optional[int] = None,
+               rng: Optional[random.Random] = None, keep_trace: bool = False) -> GenOut:
+        """`jacobi_greedy_search_multilevel` (lade/decoding.py:697-1259), single GPU or lookahead parallel."""
+        if self.lp is not None and self.lp.R > 1:
+            from .parallel import greedy_lp
+            return greedy_lp(self, prompt, max_length, eos_token_id, rng, keep_trace)
+        e, st = self.e, self.st
+        W, N, G, gs = self.W, self.N, self.G, self.gs
+        rng = rng if rng is not None else random
+        prompt = [int(t) for t in prompt]
+        dev = e.device
+        # window init: W+N-3 random prompt tokens (lade/decoding.py:887-902, `copy_from`)
+        window0 = [rng.choice(prompt) for _ in range(W + N - 3)]
+        e.reset()
+        st.reset(window0, len(prompt), prompt)
+        if self.pool_from_prompt:                                   # :915-916
+            pt = torch.tensor(prompt, dtype=torch.int32, device=dev)
+            call("lade_pool_fill_prompt", ptr(st.pool_tok), ptr(st.pool_cnt), st.V, G, gs, ptr(pt), len(prompt))
+        eos = -1 if eos_token_id is None else int(eos_token_id)
+        tokens = list(prompt)
+        steps, P, g, fill_level = 0, 0, 0, 0
+        trace: List[dict] = []
+        finished = False
+        while not finished:
+            if steps == 0:                                          # prefill: prompt + L0, plain causal
+                phase, n_input = 0, len(prompt)
+                ids_h = prompt + window0
+                T = len(ids_h)
+                st.ids[:T].copy_(torch.tensor(ids_h, dtype=torch.int32))
+                st.pos[:T].copy_(torch.arange(T, dtype=torch.int32))
+                mask = StepMask(T=T, P=0, is_prefill=True)
+                n_inp, cand_rows = len(window0), 0
+            else:
+                phase = 2 if fill_level >= N - 2 else 1
+                n_input = 1
+                ls = self._level_sizes(fill_level)
+                cand_rows = g * gs if phase == 2 else 0
+                mask = StepMask.from_levels(n_input, ls, cand_rows, gs, P)
+                T = mask.T
+                call("lade_build_inputs", None, None, n_input, ptr(st.window), st.wcap, ptr(st.ctl), min(fill_level, N - 2), 0, -1,
+                     ptr(st.guess), g if phase == 2 else 0, gs, cand_rows, ptr(st.ids), ptr(st.pos), None)
+                n_inp = ls[-1]
+            # rows whose logits are needed: out row, last level's rows, candidate rows (:1578-1606)
+            rows = [n_input - 1] + list(range(T - cand_rows - n_inp, T - cand_rows)) + list(range(T - cand_rows, T))
+            n_sel = self._set_sel(rows)
+            logits = e.forward(st.ids, st.pos, mask, st.sel, n_sel)
+            ops.argmax_rows(logits, out=st.am)
+            call("lade_greedy_post_step", ptr(st.ctl), ptr(st.window), st.wcap, ptr(st.pool_tok), ptr(st.pool_cnt), st.V, W, N, G,
+                 ptr(st.am), n_inp, ptr(st.guess), T, cand_rows, phase, int(self.pool_from_prompt), ptr(st.tail), eos, ptr(st.record))
+            ops.kv_commit(e.kv, 0, 0, 0, ctl=st.ctl)
+            rec = st.read_record()
+            steps += 1
+            max_hit, n_accept, eos_hit, g, P = rec[0], rec[1], rec[2], rec[3], rec[4]
+            accepted = rec[8:8 + n_accept]
+            tokens += accepted
+            if phase != 2:
+                fill_level += 1
+            if keep_trace:
+                trace.append(dict(T=T, P_before=mask.P, n_input=n_input, max_hit=max_hit, max_hit_idx=rec[5], accepted=list(accepted),
+                                  first_guess=rec[6], g_next=g, P_after=P))
+            if eos_hit or len(tokens) >= max_length:
+                finished = True
+        generated = min(len(tokens), max_length) - len(prompt)
+        out = GenOut(tokens=tokens[:max_length], steps=steps, generated=generated, trace=trace)
+        if CONFIG_MAP.get("DEBUG", 0):
+            CONFIG_MAP.setdefault("log", []).append([generated, steps, round(generated / steps, 2)])
+        return out

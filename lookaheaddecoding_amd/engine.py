@@ -1,0 +1,163 @@
+"""Model step of lookahead decoding on MI355X: `jforward_multilevel` re-designed.
+
+Reference: LlamaForCausalLM.jforward_multilevel -> LlamaModel.LlamaModeljforward ->
+LlamaDecoderLayer.forward -> LlamaAttention.forward (lade/models/modeling_llama.py:1381-1608,
+1108-1254, 822-899, 461-563).  There the step is ~100 small torch ops per layer, a dense fp32
+mask, a torch.cat of the whole KV cache per layer and lm_head over all T rows.  Here one step is
+
+    ids/positions (built on device)  -> embedding row gather
+    per layer:  [add+]RMSNorm (HIP) -> fused QKV GEMM (hipBLASLt via torch)
+                -> RoPE + in-place KV append (HIP) -> lookahead attention (HIP, mask in-kernel)
+                -> O GEMM -> add+RMSNorm (HIP) -> fused gate/up GEMM -> SwiGLU (HIP) -> down GEMM
+    needed rows only -> add+RMSNorm -> lm_head GEMM -> row argmax (HIP, int32 ids)
+
+with a preallocated KV cache ([L][2][Hkv*S_max*d]; keys row-major, values transposed) sized for
+the 288 GB of HBM.  The GEMMs are plain library GEMMs (weight streaming) - the
+hand-written part is everything between them.  No CPU fallback: construction fails without the
+HIP extension or without a GPU.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import cabi, ops
+from .ops import StepMask
+
+
+def rope_tables(d: int, max_pos: int, theta: float, dtype, device):
+    """cos/sin [max_pos, d]: fp32 math, then cast - exactly LlamaRotaryEmbedding
+    (lade/models/modeling_llama.py:238-256, cast at :264-265)."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+    t = torch.arange(max_pos, dtype=torch.float32)
+    freqs = torch.outer(t, inv_freq)
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos().to(dtype).to(device).contiguous(), emb.sin().to(dtype).to(device).contiguous()
+
+
+class StepEngine:
+    """Weights + KV cache + workspaces of one sequence (batch 1, as the reference asserts at
+    lade/models/modeling_llama.py:1448)."""
+
+    def __init__(self, cfg: dict, weights: Dict[str, torch.Tensor], *, dtype=torch.bfloat16, device="cuda", max_seq: int = 4096,
+                 max_T: int = 512):
+        cabi.load_library()                      # fail loudly when the HIP extension is missing
+        if not torch.cuda.is_available():
+            raise cabi.LadeHipError("StepEngine needs a GPU (MI355X); the HIP path has no CPU fallback")
+        self.cfg = dict(cfg)
+        self.dtype = dtype
+        self.device = torch.device(device)
+        self.hidden, self.inter = cfg["hidden"], cfg["inter"]
+        self.L, self.H, self.Hkv, self.d, self.V = cfg["layers"], cfg["heads"], cfg["kv_heads"], cfg["head_dim"], cfg["vocab"]
+        self.eps = float(cfg["eps"])
+        self.S_max = ((max_seq + 63) // 64) * 64
+        self.max_T = max_T
+        dev, dt = self.device, dtype
+
+        def W(k):
+            return weights[k].to(device=dev, dtype=dt)
+
+        self.embed = W("embed").contiguous()
+        self.norm_w = W("norm").contiguous()
+        self.lm_head = W("lm_head").contiguous()
+        self.layers: List[dict] = []
+        for i in range(self.L):
+            p = f"layers.{i}."
+            self.layers.append(dict(
+                ln1=W(p + "ln1").contiguous(), ln2=W(p + "ln2").contiguous(),
+                wqkv=torch.cat([W(p + "wq"), W(p + "wk"), W(p + "wv")], dim=0).contiguous(),
+                wo=W(p + "wo").contiguous(),
+                wgu=torch.cat([W(p + "wg"), W(p + "wu")], dim=0).contiguous(),
+                wd=W(p + "wd").contiguous()))
+        self.cos, self.sin = rope_tables(self.d, max(cfg.get("max_pos", 4096), self.S_max), cfg.get("rope_theta", 10000.0), dt, dev)
+        # KV cache: [L][2][Hkv*S_max*d]  (K: [Hkv][S_max][d], V: [Hkv][d][S_max]), zero-initialised
+        self.kv = torch.zeros(self.L, 2, self.Hkv * self.S_max * self.d, dtype=dt, device=dev)
+        self.kv._lade_meta = dict(Hkv=self.Hkv, d=self.d, S_max=self.S_max)
+        # workspaces (fixed addresses: graph-capturable, no allocator traffic in the loop)
+        qkv_w = (self.H + 2 * self.Hkv) * self.d
+        self.ws_x = torch.empty(max_T, self.hidden, dtype=dt, device=dev)
+        self.ws_h = torch.empty(max_T, self.hidden, dtype=dt, device=dev)
+        self.ws_r = torch.empty(max_T, self.hidden, dtype=dt, device=dev)
+        self.ws_qkv = torch.empty(max_T, qkv_w, dtype=dt, device=dev)
+        self.ws_o = torch.empty(max_T, self.H * self.d, dtype=dt, device=dev)
+        self.ws_gu = torch.empty(max_T, 2 * self.inter, dtype=dt, device=dev)
+        self.ws_a = torch.empty(max_T, self.inter, dtype=dt, device=dev)
+        self.max_splits = 32
+        if dt != torch.float32:
+            self.part_o = torch.empty(self.max_splits * self.H * max_T * self.d, dtype=torch.float32, device=dev)
+            self.part_ml = torch.empty(self.max_splits * self.H * max_T * 2, dtype=torch.float32, device=dev)
+        else:
+            self.part_o = self.part_ml = None
+        self.n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+
+    # ---- views --------------------------------------------------------------------------------
+    def k_cache(self, layer: int) -> torch.Tensor:
+        return self.kv[layer, 0].view(self.Hkv, self.S_max, self.d)
+
+    def vt_cache(self, layer: int) -> torch.Tensor:
+        return self.kv[layer, 1].view(self.Hkv, self.d, self.S_max)
+
+    def reset(self) -> None:
+        self.kv.zero_()
+
+    def n_splits_for(self, T: int, S_tot: int) -> int:
+        if self.dtype == torch.float32:
+            return 1
+        return min(ops.choose_splits(self.H, self.H // self.Hkv, T, S_tot, self.n_cu), self.max_splits)
+
+    # ---- one forward -----------------------------------------------------------------------------
+    def forward(self, ids: torch.Tensor, pos: torch.Tensor, mask: StepMask, sel_rows: torch.Tensor, n_sel: int,
+                dyn_P: Optional[torch.Tensor] = None, n_splits: Optional[int] = None) -> torch.Tensor:
+        """ids/pos: device int32 [>=T]; mask describes the step; sel_rows: device int32 [n_sel] rows whose
+        logits are needed.  Appends the T new K/V rows at P..P+T and returns logits [n_sel, V] (model dtype,
+        as `self.lm_head(hidden_states)` does at lade/models/modeling_llama.py:1541)."""
+        T, P = mask.T, mask.P
+        if T > self.max_T or P + T > self.S_max:
+            raise cabi.LadeHipError(f"step of T={T} tokens at P={P} exceeds the engine limits (max_T={self.max_T}, S_max={self.S_max})")
+        H, Hkv, d = self.H, self.Hkv, self.d
+        x, h, r = self.ws_x[:T], self.ws_h[:T], self.ws_r[:T]
+        qkv, o, gu, a = self.ws_qkv[:T], self.ws_o[:T], self.ws_gu[:T], self.ws_a[:T]
+        if n_splits is None:
+            n_splits = self.n_splits_for(T, P + T)
+        ops.gather_rows(self.embed, ids, out=x, rows=T)
+        for li, lw in enumerate(self.layers):
+            if li == 0:
+                ops.rmsnorm(x, lw["ln1"], self.eps, out=h)
+            else:
+                ops.add_rmsnorm(x, r, lw["ln1"], self.eps, out=h)          # x += mlp(prev); h = norm(x)
+            torch.matmul(h, lw["wqkv"].t(), out=qkv)
+            ops.rope_kv_append(qkv, pos, self.cos, self.sin, self.k_cache(li), self.vt_cache(li), P, H=H, Hkv=Hkv, d=d, dyn_P=dyn_P)
+            ops.attn_fwd(qkv, self.k_cache(li), self.vt_cache(li), mask, H=H, Hkv=Hkv, d=d, out=o, n_splits=n_splits,
+                         part_o=self.part_o, part_ml=self.part_ml, dyn_P=dyn_P)
+            torch.matmul(o, lw["wo"].t(), out=r)
+            ops.add_rmsnorm(x, r, lw["ln2"], self.eps, out=h)              # x += attn; h = norm(x)
+            torch.matmul(h, lw["wgu"].t(), out=gu)
+            ops.silu_mul(gu, out=a)
+            torch.matmul(a, lw["wd"].t(), out=r)
+        xs = ops.gather_rows(x, sel_rows, rows=n_sel)
+        rs = ops.gather_rows(r, sel_rows, rows=n_sel)
+        hn = ops.add_rmsnorm(xs, rs, self.norm_w, self.eps)
+        return torch.matmul(hn, self.lm_head.t())
+
+    # ---- plain causal decoding on the same kernels (the sequence lookahead must reproduce) ------
+    @torch.no_grad()
+    def plain_greedy(self, prompt: Sequence[int], max_length: int, eos_token_id: Optional[int] = None) -> List[int]:
+        self.reset()
+        ids = list(prompt)
+        feed = list(prompt)
+        P = 0
+        while len(ids) < max_length:
+            T = len(feed)
+            t_ids = torch.tensor(feed, dtype=torch.int32, device=self.device)
+            t_pos = torch.arange(P, P + T, dtype=torch.int32, device=self.device)
+            sel = torch.tensor([T - 1], dtype=torch.int32, device=self.device)
+            logits = self.forward(t_ids, t_pos, StepMask(T=T, P=P, is_prefill=True), sel, 1)
+            nxt = int(ops.argmax_rows(logits)[0].item())
+            ids.append(nxt)
+            P += T
+            feed = [nxt]
+            if eos_token_id is not None and nxt == eos_token_id:
+                break
+        return ids

@@ -1,0 +1,178 @@
+"""Tensor-level wrappers over the C ABI (one python function per HIP entry point).
+
+Every function validates shapes/dtypes on the host, passes raw device pointers to liblade_hip.so
+and returns torch tensors that live on the GPU.  Nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import cabi
+from .cabi import AttnArgs, MaskParams, call, dtype_code, ptr
+
+
+@dataclass
+class StepMask:
+    """Closed-form description of the lookahead mask of one step (see include/lade_hip.h).
+    Reference: j_make_causal_mask_multilevel, lade/models/modeling_llama.py:115-207."""
+    T: int
+    P: int
+    is_prefill: bool
+    s: int = 1
+    lguess: int = 0
+    gs: int = 1
+    level_offset: int = 0
+    dist_offset: int = 0
+
+    @staticmethod
+    def from_levels(n_input: int, level_sizes, lguess: int, gs: int, P: int, is_prefill: bool = False) -> "StepMask":
+        T = n_input + sum(level_sizes) + lguess
+        return StepMask(T=T, P=P, is_prefill=is_prefill, s=level_sizes[-1], lguess=lguess, gs=gs, level_offset=n_input - 1,
+                        dist_offset=1 + level_sizes[0] - level_sizes[-1])
+
+    def c_struct(self) -> MaskParams:
+        return MaskParams(self.T, self.P, int(self.is_prefill), self.s, self.lguess, self.gs, self.level_offset, self.dist_offset)
+
+
+def _dev(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise cabi.LadeHipError(f"{name} must be a GPU tensor (the HIP path has no CPU fallback)")
+
+
+def choose_splits(H: int, n_rep: int, T: int, S_tot: int, n_cu: int = 256) -> int:
+    """KV splits so that (row blocks x KV heads x splits) fills the 256 CUs without making a split
+    shorter than one 64-key tile."""
+    blocks = (H // n_rep) * ((n_rep * T + 127) // 128)
+    tiles = max(1, (S_tot + 63) // 64)
+    want = max(1, (n_cu + blocks - 1) // blocks)
+    return max(1, min(want, tiles, 32))
+
+
+def attn_fwd(q: torch.Tensor, k_cache: torch.Tensor, vt_cache: torch.Tensor, mask: StepMask, *, H: int, Hkv: int, d: int,
+             out: Optional[torch.Tensor] = None, n_splits: Optional[int] = None, scale: Optional[float] = None,
+             q_row_stride: Optional[int] = None, part_o: Optional[torch.Tensor] = None, part_ml: Optional[torch.Tensor] = None,
+             dyn_P: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Lookahead attention for one step.  q: [T, >=H*d] rows (token stride q_row_stride elements, default
+    q.stride(0)); k_cache [Hkv, S_max, d]; vt_cache [Hkv, d, S_max]; returns out [T, H*d]."""
+    for n, t in (("q", q), ("k_cache", k_cache), ("vt_cache", vt_cache)):
+        _dev(t, n)
+    T = mask.T
+    S_max = k_cache.shape[1]
+    assert k_cache.shape == (Hkv, S_max, d) and vt_cache.shape == (Hkv, d, S_max), (k_cache.shape, vt_cache.shape)
+    assert k_cache.is_contiguous() and vt_cache.is_contiguous() and q.stride(-1) == 1
+    if out is None:
+        out = torch.empty(T, H * d, dtype=q.dtype, device=q.device)
+    if n_splits is None:
+        n_splits = 1 if q.dtype == torch.float32 else choose_splits(H, H // Hkv, T, mask.P + T)
+    if q.dtype == torch.float32:
+        n_splits = 1
+    if n_splits > 1:
+        if part_o is None:
+            part_o = torch.empty(n_splits, H, T, d, dtype=torch.float32, device=q.device)
+        if part_ml is None:
+            part_ml = torch.empty(n_splits, H, T, 2, dtype=torch.float32, device=q.device)
+    a = AttnArgs(ptr(q), ptr(k_cache), ptr(vt_cache), ptr(out), ptr(part_o), ptr(part_ml), ptr(dyn_P),
+                 q_row_stride if q_row_stride is not None else q.stride(0), out.stride(0), H, Hkv, d, S_max,
+                 dtype_code(q), n_splits, scale if scale is not None else 1.0 / math.sqrt(d), mask.c_struct())
+    call("lade_attn_fwd", C.byref(a))
+    if n_splits > 1:
+        call("lade_attn_combine", C.byref(a))
+    return out
+
+
+def time_attn(q, k_cache, vt_cache, mask: StepMask, *, H, Hkv, d, n_splits: int, reps: int = 20) -> float:
+    """Mean duration in microseconds of one attention launch (+combine), measured with hipEvents on the
+    launch stream inside the library."""
+    T, S_max = mask.T, k_cache.shape[1]
+    out = torch.empty(T, H * d, dtype=q.dtype, device=q.device)
+    part_o = torch.empty(max(n_splits, 1), H, T, d, dtype=torch.float32, device=q.device)
+    part_ml = torch.empty(max(n_splits, 1), H, T, 2, dtype=torch.float32, device=q.device)
+    a = AttnArgs(ptr(q), ptr(k_cache), ptr(vt_cache), ptr(out), ptr(part_o), ptr(part_ml), None, q.stride(0), out.stride(0),
+                 H, Hkv, d, S_max, dtype_code(q), n_splits, 1.0 / math.sqrt(d), mask.c_struct())
+    us = C.c_float(0.0)
+    call("lade_time_attn", C.byref(a), reps, C.byref(us))
+    return float(us.value)
+
+
+def mask_render(mask: StepMask, device="cuda") -> torch.Tensor:
+    out = torch.zeros(mask.T, mask.P + mask.T, dtype=torch.uint8, device=device)
+    m = mask.c_struct()
+    call("lade_mask_render", C.byref(m), ptr(out))
+    return out
+
+
+def rope_kv_append(qkv: torch.Tensor, positions: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, k_cache: torch.Tensor,
+                   vt_cache: torch.Tensor, P: int, *, H: int, Hkv: int, d: int, dyn_P: Optional[torch.Tensor] = None) -> None:
+    """qkv [T, (H+2Hkv)*d] (q rotated in place); k_cache [Hkv,S_max,d]; vt_cache [Hkv,d,S_max]."""
+    _dev(qkv, "qkv")
+    T = qkv.shape[0]
+    assert qkv.is_contiguous() and qkv.shape[1] == (H + 2 * Hkv) * d
+    assert positions.dtype == torch.int32 and positions.numel() >= T
+    assert cos.dtype == qkv.dtype and cos.shape[1] == d and cos.is_contiguous() and sin.is_contiguous()
+    call("lade_rope_kv_append", ptr(qkv), ptr(positions), ptr(cos), ptr(sin), ptr(k_cache), ptr(vt_cache), T, P, ptr(dyn_P), H, Hkv,
+         d, k_cache.shape[1], cos.shape[0], dtype_code(qkv))
+
+
+def kv_commit(cache: torch.Tensor, src: int, dst: int, cnt: int, ctl: Optional[torch.Tensor] = None) -> None:
+    """cache [L, 2, Hkv*S_max*d] viewed as K [Hkv,S_max,d] / V^T [Hkv,d,S_max] per layer."""
+    L = cache.shape[0]
+    meta = cache._lade_meta
+    call("lade_kv_commit", ptr(cache), cache.stride(0), cache.stride(1), L, meta["Hkv"], meta["d"], meta["S_max"], src, dst, cnt,
+         ptr(ctl), 0, cache.element_size())
+
+
+def argmax_rows(logits: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _dev(logits, "logits")
+    assert logits.dim() == 2 and logits.stride(1) == 1
+    rows, V = logits.shape
+    if out is None:
+        out = torch.empty(rows, dtype=torch.int32, device=logits.device)
+    call("lade_argmax_rows", ptr(logits), logits.stride(0), rows, V, dtype_code(logits), ptr(out))
+    return out
+
+
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    assert x.is_contiguous() and x.dim() == 2
+    if out is None:
+        out = torch.empty_like(x)
+    call("lade_rmsnorm", ptr(x), ptr(w), ptr(out), x.shape[0], x.shape[1], eps, dtype_code(x))
+    return out
+
+
+def add_rmsnorm(x: torch.Tensor, r: torch.Tensor, w: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x += r (in place); returns rmsnorm(x)."""
+    assert x.is_contiguous() and r.is_contiguous() and x.shape == r.shape
+    if out is None:
+        out = torch.empty_like(x)
+    call("lade_add_rmsnorm", ptr(x), ptr(r), ptr(w), ptr(out), x.shape[0], x.shape[1], eps, dtype_code(x))
+    return out
+
+
+def silu_mul(gu: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    assert gu.is_contiguous() and gu.shape[1] % 2 == 0
+    inter = gu.shape[1] // 2
+    if out is None:
+        out = torch.empty(gu.shape[0], inter, dtype=gu.dtype, device=gu.device)
+    call("lade_silu_mul", ptr(gu), ptr(out), gu.shape[0], inter, dtype_code(gu))
+    return out
+
+
+def gather_rows(src: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = None, rows: Optional[int] = None) -> torch.Tensor:
+    assert src.is_contiguous() and idx.dtype == torch.int32
+    rows = idx.numel() if rows is None else rows
+    if out is None:
+        out = torch.empty(rows, src.shape[1], dtype=src.dtype, device=src.device)
+    call("lade_gather_rows", ptr(src), ptr(idx), ptr(out), rows, src.shape[1], src.element_size(), src.shape[0])
+    return out
+
+
+def softmax_rows(logits: torch.Tensor, temperature: float = 1.0) -> torch.Tensor:
+    assert logits.dim() == 2 and logits.stride(1) == 1
+    probs = torch.empty(logits.shape, dtype=torch.float32, device=logits.device)
+    call("lade_softmax_rows", ptr(logits), logits.stride(0), logits.shape[0], logits.shape[1], dtype_code(logits), float(temperature), ptr(probs))
+    return probs

@@ -1,0 +1,396 @@
+"""Kernel-level parity of liblade_hip.so against the CPU oracle and the reference-generated golden
+fixtures.  Integer kernels: bit-exact.  Attention: tolerance stated per dtype."""
+import json
+import math
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import lade_oracle as O
+from conftest import GOLDEN
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from lookaheaddecoding_amd import cabi
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return cabi.load_library()
+
+
+def dev(x, dtype=torch.int32):
+    return torch.as_tensor(x, dtype=dtype).cuda()
+
+
+def load(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+# ---------------------------------------------------------------- mask predicate (bit-exact vs reference masks)
+
+def test_mask_predicate_matches_reference_masks(lib):
+    from lookaheaddecoding_amd import ops
+    d = load("mask_cases.json")
+    for c in d["cases"]:
+        m = ops.StepMask(T=c["T"], P=c["P"], is_prefill=False, s=c["level_sizes"][-1], lguess=c["lguess"], gs=c["gs"],
+                         level_offset=c["level_offset"], dist_offset=1 + c["level_sizes"][0] - c["level_sizes"][-1])
+        got = ops.mask_render(m).cpu().numpy().astype(bool)
+        rows = [format(int("".join("1" if b else "0" for b in r), 2), "x") for r in got.tolist()]
+        assert rows == c["rows"], c
+    got = ops.mask_render(ops.StepMask(T=9, P=0, is_prefill=True)).cpu().numpy().astype(bool)
+    assert [format(int("".join("1" if b else "0" for b in r), 2), "x") for r in got.tolist()] == d["prefill_T9"]
+
+
+# ---------------------------------------------------------------- attention
+
+def _layouts():
+    """(name, n_input, level_sizes, lguess, gs, is_prefill)"""
+    return [
+        ("steady_c2", 1, [14, 15, 15, 15], 60, 4, False),          # BASELINE config 2, g = G
+        ("steady_c2_g0", 1, [14, 15, 15, 15], 0, 4, False),
+        ("steady_c1", 1, [4, 5], 6, 2, False),                      # config 1 (W=5 N=3 G=3)
+        ("fill", 1, [16, 17, 17], 0, 4, False),
+        ("lp_shard", 1, [7, 2, 2, 2], 8, 4, False),                 # rank with window columns 6..8, dist_offset 6
+        ("lp_refeed", 4, [3, 2, 2, 2], 8, 4, False),                # level_offset 3 (re-fed hits)
+        ("prefill", 37, [20], 0, 4, True),
+        ("c4_big", 1, [19] + [20] * 5, 120, 6, False),              # config 4: T = 240
+    ]
+
+
+def _attn_case(name, n_input, ls, lguess, gs, is_prefill, H, Hkv, dh, P, dtype, seed, n_splits, S_max=None):
+    from lookaheaddecoding_amd import ops
+    torch.manual_seed(seed)
+    lay = O.StepLayout(ids=[0] * (n_input + sum(ls) + lguess), positions=[], n_input=n_input, level_sizes=ls, lguess=lguess,
+                       is_prefill=is_prefill, window=ls[-1])
+    T = lay.T
+    vis = O.dense_mask(lay, P, gs)
+    S = P + T
+    S_max = S_max or ((S + 63) // 64 * 64 + 64)
+    q = torch.randn(T, H, dh)
+    k = torch.randn(Hkv, S_max, dh)
+    v = torch.randn(Hkv, S_max, dh)
+    qd, kd, vd = q.to(dtype), k.to(dtype), v.to(dtype)
+    ref = O.attention_dense(qd.float().transpose(0, 1), kd.float()[:, :S], vd.float()[:, :S], vis).transpose(0, 1).reshape(T, H * dh)
+    m = ops.StepMask.from_levels(n_input, ls, lguess, gs, P, is_prefill) if not is_prefill else ops.StepMask(T=T, P=P, is_prefill=True)
+    out = ops.attn_fwd(qd.reshape(T, H * dh).cuda(), kd.cuda().contiguous(), vd.transpose(1, 2).contiguous().cuda(), m, H=H, Hkv=Hkv, d=dh,
+                       n_splits=n_splits)
+    return out.float().cpu(), ref
+
+
+TOL = {torch.bfloat16: dict(atol=2e-2, rtol=2e-2), torch.float16: dict(atol=4e-3, rtol=1e-2), torch.float32: dict(atol=2e-5, rtol=1e-4)}
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("lay", _layouts(), ids=lambda l: l[0])
+def test_attention_vs_oracle(lib, dtype, lay):
+    name, n_input, ls, lguess, gs, is_prefill = lay
+    for (H, Hkv, dh) in ((4, 4, 128), (8, 2, 64)):
+        for P, n_splits in ((0 if is_prefill else 3, 1), (200, 3), (1021, None)):
+            if is_prefill and P > 0 and n_splits == 3:
+                continue
+            if dtype == torch.float32 and P > 200:
+                continue
+            out, ref = _attn_case(name, n_input, ls, lguess, gs, is_prefill, H, Hkv, dh, P, dtype, seed=hash((name, P)) % 1000, n_splits=n_splits)
+            assert torch.isfinite(out).all()
+            assert torch.allclose(out, ref, **TOL[dtype]), (name, H, Hkv, dh, P, n_splits, (out - ref).abs().max().item())
+
+
+def test_attention_stale_cache_rows_are_ignored(lib):
+    """rows >= P+T of the cache hold garbage (NaN): they must not leak into the result."""
+    from lookaheaddecoding_amd import ops
+    torch.manual_seed(3)
+    H, dh, P, T = 2, 128, 70, 60 + 8
+    ls, lguess, gs = [14, 15, 15, 15], 8, 4
+    lay = O.StepLayout(ids=[0] * T, positions=[], n_input=1, level_sizes=ls, lguess=lguess, is_prefill=False, window=15)
+    vis = O.dense_mask(lay, P, gs)
+    S, S_max = P + T, 256
+    q = torch.randn(T, H, dh).bfloat16()
+    k = torch.full((H, S_max, dh), float("nan")).bfloat16()
+    v = torch.full((H, S_max, dh), float("nan")).bfloat16()
+    k[:, :S] = torch.randn(H, S, dh).bfloat16()
+    v[:, :S] = torch.randn(H, S, dh).bfloat16()
+    ref = O.attention_dense(q.float().transpose(0, 1), k.float()[:, :S], v.float()[:, :S], vis).transpose(0, 1).reshape(T, H * dh)
+    for ns in (1, 2):
+        out = ops.attn_fwd(q.reshape(T, -1).cuda(), k.cuda(), v.transpose(1, 2).contiguous().cuda(), ops.StepMask.from_levels(1, ls, lguess, gs, P),
+                           H=H, Hkv=H, d=dh, n_splits=ns).float().cpu()
+        assert torch.isfinite(out).all()
+        assert torch.allclose(out, ref, **TOL[torch.bfloat16])
+
+
+def test_attention_online_softmax_rescale_is_exercised(lib):
+    """one key far above the rest, late in the stream: forces the running-max rescale branch."""
+    from lookaheaddecoding_amd import ops
+    torch.manual_seed(5)
+    H, dh, P, T = 1, 128, 500, 8
+    q = torch.randn(T, H, dh).bfloat16()
+    k = (torch.randn(H, 576, dh) * 0.3).bfloat16()
+    v = torch.randn(H, 576, dh).bfloat16()
+    k[0, 450] = (q[3, 0].float() * 1.5).bfloat16()       # spikes row 3 at key 450 (tile 7)
+    vis = np.zeros((T, P + T), dtype=bool); vis[:, :P] = True; vis[:, P:] = np.tril(np.ones((T, T), dtype=bool))
+    ref = O.attention_dense(q.float().transpose(0, 1), k.float()[:, :P + T], v.float()[:, :P + T], vis).transpose(0, 1).reshape(T, -1)
+    out = ops.attn_fwd(q.reshape(T, -1).cuda(), k.cuda(), v.transpose(1, 2).contiguous().cuda(), ops.StepMask(T=T, P=P, is_prefill=True), H=H, Hkv=H,
+                       d=dh, n_splits=1).float().cpu()
+    assert torch.allclose(out, ref, **TOL[torch.bfloat16]), (out - ref).abs().max()
+
+
+def test_attention_and_rope_vs_reference_capture(lib):
+    """q/k/v projections, cache and attention output captured inside the reference's own LlamaAttention.forward."""
+    from lookaheaddecoding_amd import ops
+    from lookaheaddecoding_amd.engine import rope_tables
+    from lookaheaddecoding_amd.weights import make_config
+    z = np.load(os.path.join(GOLDEN, "attn_steps.npz"))
+    d = load("e2e_greedy.json")
+    keys = sorted({k.rsplit(".", 2)[0] for k in z.files})
+    for base in keys:
+        mname, W, N, G, seed, step = base.split(".")
+        W, N, G, seed, step = int(W), int(N), int(G), int(seed[1:]), int(step[4:])
+        run = [r for r in d["runs"] if r["model"] == mname and (r["W"], r["N"], r["G"], r["seed"]) == (W, N, G, seed) and r["eos"] is None][0]
+        tr = run["trace"][step]
+        cfg = make_config(mname, max_pos=512)
+        H, Hkv, dh = cfg["heads"], cfg["kv_heads"], cfg["head_dim"]
+        T, P = len(tr["ids"]), tr["P"]
+        S_max = 128
+        for dtype in (torch.float32, torch.bfloat16):
+            cos, sin = rope_tables(dh, 512, cfg["rope_theta"], dtype, "cuda")
+            mask = ops.StepMask(T=T, P=P, is_prefill=True) if tr["is_prefill"] else ops.StepMask.from_levels(tr["n_input"], tr["level_sizes"], tr["lguess"], N - 1, P)
+            for li in range(cfg["layers"]):
+                qkv = torch.cat([torch.as_tensor(z[f"{base}.L{li}.{n}"]) for n in ("q_proj", "k_proj", "v_proj")], dim=1).to(dtype).cuda().contiguous()
+                Kref = torch.as_tensor(z[f"{base}.L{li}.K"])
+                Vref = torch.as_tensor(z[f"{base}.L{li}.V"])
+                kc = torch.zeros(Hkv, S_max, dh, dtype=dtype, device="cuda")
+                vt = torch.zeros(Hkv, dh, S_max, dtype=dtype, device="cuda")
+                kc[:, :P] = Kref[:, :P].to(dtype)
+                vt[:, :, :P] = Vref[:, :P].transpose(1, 2).to(dtype)
+                ops.rope_kv_append(qkv, dev(tr["positions"]), cos, sin, kc, vt, P, H=H, Hkv=Hkv, d=dh)
+                tol = dict(atol=1e-6, rtol=1e-5) if dtype == torch.float32 else dict(atol=3e-2, rtol=3e-2)
+                assert torch.allclose(kc[:, :P + T].float().cpu(), Kref, **tol)
+                assert torch.allclose(vt[:, :, :P + T].float().cpu().transpose(1, 2), Vref, **tol)
+                out = ops.attn_fwd(qkv, kc, vt, mask, H=H, Hkv=Hkv, d=dh).float().cpu()
+                ref = torch.as_tensor(z[f"{base}.L{li}.attn_out"])
+                tol = dict(atol=5e-6, rtol=1e-4) if dtype == torch.float32 else dict(atol=3e-2, rtol=3e-2)
+                assert torch.allclose(out, ref, **tol), (base, li, dtype, (out - ref).abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_rope_kv_append_bit_exact_vs_torch_semantics(lib, dtype):
+    """same rounding sequence as the reference's torch ops in the model dtype (modeling_llama.py:342-346)."""
+    from lookaheaddecoding_amd import ops
+    from lookaheaddecoding_amd.engine import rope_tables
+    torch.manual_seed(1)
+    H, Hkv, dh, T, P, S_max = 4, 2, 64, 23, 17, 128
+    cos, sin = rope_tables(dh, 256, 10000.0, dtype, "cpu")
+    qkv = torch.randn(T, (H + 2 * Hkv) * dh).to(dtype)
+    pos = torch.tensor([random.Random(2).randrange(200) for _ in range(T)])
+    q = qkv[:, :H * dh].view(T, H, dh).transpose(0, 1)
+    k = qkv[:, H * dh:(H + Hkv) * dh].view(T, Hkv, dh).transpose(0, 1)
+    v = qkv[:, (H + Hkv) * dh:].view(T, Hkv, dh).transpose(0, 1)
+    rq = (q * cos[pos][None]) + (O.rotate_half(q) * sin[pos][None])
+    rk = (k * cos[pos][None]) + (O.rotate_half(k) * sin[pos][None])
+    kc = torch.zeros(Hkv, S_max, dh, dtype=dtype, device="cuda")
+    vt = torch.zeros(Hkv, dh, S_max, dtype=dtype, device="cuda")
+    qkv_d = qkv.cuda().contiguous()
+    ops.rope_kv_append(qkv_d, dev(pos.tolist()), cos.cuda(), sin.cuda(), kc, vt, P, H=H, Hkv=Hkv, d=dh)
+    got_q = qkv_d[:, :H * dh].view(T, H, dh).transpose(0, 1).cpu()
+    assert torch.equal(got_q, rq)
+    assert torch.equal(kc[:, P:P + T].cpu(), rk)
+    assert torch.equal(vt[:, :, P:P + T].cpu(), v.transpose(1, 2))
+    assert (kc[:, :P] == 0).all() and (kc[:, P + T:] == 0).all()
+
+
+def test_kv_commit(lib):
+    from lookaheaddecoding_amd import ops
+    L, Hkv, dh, S_max = 3, 2, 64, 128
+    kv = torch.randn(L, 2, Hkv * S_max * dh, device="cuda").bfloat16()
+    kv._lade_meta = dict(Hkv=Hkv, d=dh, S_max=S_max)
+    ref = kv.clone()
+    src, dst, cnt = 90, 40, 3
+    ops.kv_commit(kv, src, dst, cnt)
+    K = ref[:, 0].view(L, Hkv, S_max, dh).clone(); K[:, :, dst:dst + cnt] = K[:, :, src:src + cnt]
+    Vt = ref[:, 1].view(L, Hkv, dh, S_max).clone(); Vt[:, :, :, dst:dst + cnt] = Vt[:, :, :, src:src + cnt]
+    assert torch.equal(kv[:, 0].view(L, Hkv, S_max, dh), K)
+    assert torch.equal(kv[:, 1].view(L, Hkv, dh, S_max), Vt)
+    ctl = torch.zeros(64, dtype=torch.int32, device="cuda"); ctl[10], ctl[11], ctl[12] = 100, 50, 2
+    ops.kv_commit(kv, 0, 0, 0, ctl=ctl)
+    K[:, :, 50:52] = K[:, :, 100:102]; Vt[:, :, :, 50:52] = Vt[:, :, :, 100:102]
+    assert torch.equal(kv[:, 0].view(L, Hkv, S_max, dh), K) and torch.equal(kv[:, 1].view(L, Hkv, dh, S_max), Vt)
+
+
+# ---------------------------------------------------------------- integer kernels (bit-exact)
+
+def _pool_to_dict(pool_tok, pool_cnt):
+    cnt = pool_cnt.cpu().tolist()
+    tok = pool_tok.cpu()
+    return {str(k): [tok[k, j].tolist() for j in range(c)] for k, c in enumerate(cnt) if c > 0}
+
+
+def test_pool_kats_bit_exact(lib):
+    """replays the reference-generated pool KATs (update_token_map / fill_pool_with_prompt /
+    append_new_generated_pool) on the device pool; state compared after every op, order included."""
+    from lookaheaddecoding_amd.cabi import call, ptr
+    d = load("pool_kat.json")
+    n = 0
+    for case in d["cases"]:
+        N, W, G = case["LEVEL"], case["W"], case["G"]
+        gs = N - 1
+        V = 1024
+        pool_tok = torch.zeros(V, G, gs, dtype=torch.int32, device="cuda")
+        pool_cnt = torch.zeros(V, dtype=torch.int32, device="cuda")
+        wcap = W + N
+        for op in case["ops"]:
+            if op["op"] == "update":
+                win = torch.zeros(N - 1, wcap, dtype=torch.int32)
+                for l, lv in enumerate(op["past"]):
+                    win[l, :len(lv)] = torch.tensor(lv, dtype=torch.int32)
+                call("lade_pool_insert_window", ptr(pool_tok), ptr(pool_cnt), V, G, gs, ptr(dev([op["lst"]])), ptr(win.cuda()), wcap,
+                     ptr(dev(op["new"])), W, N)
+            elif op["op"] == "prompt":
+                if len(op["prompts"]) > 0:
+                    call("lade_pool_fill_prompt", ptr(pool_tok), ptr(pool_cnt), V, G, gs, ptr(dev(op["prompts"])), len(op["prompts"]))
+            else:
+                if len(op["tokens"]) == N:
+                    call("lade_pool_insert_ngrams", ptr(pool_tok), ptr(pool_cnt), V, G, gs, ptr(dev(op["tokens"])), 1)
+            assert _pool_to_dict(pool_tok, pool_cnt) == op["after"], (case["LEVEL"], case["W"], case["G"], op["op"])
+            n += 1
+    assert n > 80
+
+
+def test_pool_lookup_and_verify_vs_oracle(lib):
+    from lookaheaddecoding_amd.cabi import call, ptr
+    rs = random.Random(7)
+    for trial in range(60):
+        N = rs.choice([3, 4, 5, 7]); gs = N - 1; G = rs.choice([1, 3, 7, 15, 20])
+        g = rs.randrange(0, G + 1)
+        vocab = rs.choice([2, 3, 50])
+        guess = [rs.randrange(vocab) for _ in range(g * gs)]
+        am = [rs.randrange(vocab) for _ in range(g * gs)]
+        fg = rs.randrange(vocab)
+        if g > 0 and rs.random() < 0.5:          # plant a long match
+            e = rs.randrange(g); ln = rs.randrange(1, gs + 1)
+            guess[e * gs] = fg
+            for j in range(1, ln):
+                am[e * gs + j - 1] = guess[e * gs + j]
+        exp = O.greedy_verify(fg, guess if g > 0 else None, am, gs)
+        out2 = torch.zeros(2, dtype=torch.int32, device="cuda"); hits = torch.zeros(gs, dtype=torch.int32, device="cuda")
+        call("lade_verify_greedy", ptr(dev([fg])), ptr(dev(guess + [0])), ptr(dev(am + [0])), g, gs, ptr(out2), ptr(hits))
+        mh, mi = out2.cpu().tolist()
+        assert (mh, hits.cpu().tolist()) == (exp[0], exp[2]), (trial, guess, am, fg)
+        if exp[0] > 0:
+            assert mi == exp[1]
+    # lookup: order and count
+    V, G, gs = 64, 4, 3
+    tm = {}
+    pool_tok = torch.zeros(V, G, gs, dtype=torch.int32, device="cuda"); pool_cnt = torch.zeros(V, dtype=torch.int32, device="cuda")
+    grams = [[5, 1, 2, 3], [5, 4, 5, 6], [7, 1, 1, 1], [5, 1, 2, 3], [5, 9, 9, 9], [5, 8, 8, 8], [5, 7, 7, 7]]
+    for gtoks in grams:
+        O.append_new_generated_pool(gtoks, tm, 4, G)
+    call("lade_pool_insert_ngrams", ptr(pool_tok), ptr(pool_cnt), V, G, gs, ptr(dev(sum(grams, []))), len(grams))
+    for key in (5, 7, 9):
+        go = torch.zeros(G * gs, dtype=torch.int32, device="cuda"); gn = torch.zeros(1, dtype=torch.int32, device="cuda")
+        call("lade_pool_lookup", ptr(pool_tok), ptr(pool_cnt), V, G, gs, ptr(dev([key])), ptr(go), ptr(gn))
+        exp = O.pool_lookup(tm, key, True, G) or []
+        assert gn.item() == len(exp) // gs and go.cpu().tolist()[:len(exp)] == exp
+
+
+def test_window_fill_roll_and_build_inputs_vs_oracle(lib):
+    from lookaheaddecoding_amd.cabi import CTL_WLEN, CTL_WORDS, CTL_LST_POS, CTL_LST_TOKEN, call, ptr
+    rs = random.Random(11)
+    for (W, N) in ((5, 4), (15, 5), (3, 3), (20, 7)):
+        gs = N - 1
+        wcap = W + N - 3
+        past = [[rs.randrange(100) for _ in range(wcap)]] + [None] * (N - 2)
+        window = torch.zeros(N - 1, wcap, dtype=torch.int32); window[0] = torch.tensor(past[0], dtype=torch.int32)
+        window = window.cuda()
+        ctl = torch.zeros(CTL_WORDS, dtype=torch.int32); ctl[CTL_WLEN] = wcap; ctl[CTL_LST_POS] = 41; ctl[CTL_LST_TOKEN] = 77
+        ctl = ctl.cuda()
+
+        def check():
+            c = ctl.cpu().tolist(); w = window.cpu()
+            for l, lv in enumerate(past):
+                if lv is not None:
+                    assert c[CTL_WLEN + l] == len(lv) and w[l, :len(lv)].tolist() == lv, (W, N, l)
+
+        inp = [rs.randrange(100) for _ in range(wcap)]
+        O.window_fill_first(past, inp)
+        call("lade_window_fill_first", ptr(window), wcap, ptr(ctl), ptr(dev(inp)), len(inp))
+        check()
+        fill_level = 1
+        while past[N - 2] is None:
+            inp = [rs.randrange(100) for _ in range(len(past[fill_level]))]
+            # inputs for this fill step, before the update
+            guess = None
+            lay = O.build_step_layout([77], [41], past, None, fill_level, gs)
+            ids = torch.zeros(256, dtype=torch.int32, device="cuda"); pos = torch.zeros(256, dtype=torch.int32, device="cuda"); oT = torch.zeros(1, dtype=torch.int32, device="cuda")
+            call("lade_build_inputs", None, None, 1, ptr(window), wcap, ptr(ctl), fill_level, 0, -1, None, 0, gs, -1, ptr(ids), ptr(pos), ptr(oT))
+            assert oT.item() == lay.T and ids[:lay.T].cpu().tolist() == lay.ids and pos[:lay.T].cpu().tolist() == lay.positions
+            O.window_fill(past, fill_level, inp)
+            call("lade_window_fill", ptr(window), wcap, ptr(ctl), fill_level, ptr(dev(inp)), len(inp))
+            fill_level += 1
+            check()
+        for it in range(3):
+            g = rs.randrange(0, 4)
+            guess = [rs.randrange(100) for _ in range(g * gs)]
+            lay = O.build_step_layout([77], [41], past, guess if g else None, N - 2, gs)
+            ids = torch.zeros(512, dtype=torch.int32, device="cuda"); pos = torch.zeros(512, dtype=torch.int32, device="cuda"); oT = torch.zeros(1, dtype=torch.int32, device="cuda")
+            call("lade_build_inputs", None, None, 1, ptr(window), wcap, ptr(ctl), N - 2, 0, -1, ptr(dev(guess + [0])), g, gs, -1, ptr(ids), ptr(pos), ptr(oT))
+            assert oT.item() == lay.T and ids[:lay.T].cpu().tolist() == lay.ids and pos[:lay.T].cpu().tolist() == lay.positions
+            # lookahead-parallel shards of the same window
+            for R in (2, 3):
+                for r in range(R):
+                    pt, ws, we = O.lp_window_shard(past, R, r)
+                    lay = O.build_step_layout([77], [41], pt, None, N - 2, gs)
+                    call("lade_build_inputs", None, None, 1, ptr(window), wcap, ptr(ctl), N - 2, ws, we, None, 0, gs, -1, ptr(ids), ptr(pos), ptr(oT))
+                    assert oT.item() == lay.T and ids[:lay.T].cpu().tolist() == lay.ids and pos[:lay.T].cpu().tolist() == lay.positions, (W, N, R, r)
+            new = [rs.randrange(100) for _ in range(W)]
+            O.window_roll(past, new, N)
+            call("lade_window_roll", ptr(window), wcap, ptr(ctl), ptr(dev(new)), W, N)
+            check()
+
+
+def test_argmax_rows_first_index_ties(lib):
+    from lookaheaddecoding_amd import ops
+    torch.manual_seed(0)
+    for dtype in (torch.bfloat16, torch.float16, torch.float32):
+        x = torch.randn(37, 32000).to(dtype)
+        x[3, 100] = x[3, 20000] = 50.0          # tie: first index wins
+        x[5, :] = 1.0                            # all equal
+        x[7, 31999] = 60.0
+        got = ops.argmax_rows(x.cuda()).cpu().long()
+        assert torch.equal(got, torch.argmax(x.float(), dim=-1))
+        assert got[3] == 100 and got[5] == 0 and got[7] == 31999
+    x = torch.randn(5, 130).bfloat16()
+    xs = torch.zeros(5, 200, dtype=torch.bfloat16); xs[:, :130] = x; xs[:, 130:] = 99.0
+    assert torch.equal(ops.argmax_rows(xs.cuda()[:, :130]).cpu().long(), torch.argmax(x.float(), dim=-1))
+
+
+def test_glue_kernels_vs_torch(lib):
+    from lookaheaddecoding_amd import ops
+    torch.manual_seed(0)
+    for dtype in (torch.bfloat16, torch.float16, torch.float32):
+        x = torch.randn(19, 384).to(dtype); r = torch.randn(19, 384).to(dtype); w = (1 + 0.1 * torch.randn(384)).to(dtype)
+
+        def ref_norm(h):
+            v = h.float().pow(2).mean(-1, keepdim=True)
+            return w * (h.float() * torch.rsqrt(v + 1e-5)).to(dtype)
+
+        y = ops.rmsnorm(x.cuda(), w.cuda(), 1e-5).cpu()
+        tol = dict(atol=1e-6, rtol=1e-5) if dtype == torch.float32 else dict(atol=2e-2, rtol=2e-2)
+        assert torch.allclose(y.float(), ref_norm(x).float(), **tol)
+        xd = x.cuda().clone()
+        y2 = ops.add_rmsnorm(xd, r.cuda(), w.cuda(), 1e-5).cpu()
+        assert torch.equal(xd.cpu(), x + r)
+        assert torch.allclose(y2.float(), ref_norm(x + r).float(), **tol)
+        gu = torch.randn(7, 2 * 176).to(dtype)
+        act = ops.silu_mul(gu.cuda()).cpu()
+        exp = torch.nn.functional.silu(gu[:, :176]) * gu[:, 176:]
+        assert torch.allclose(act.float(), exp.float(), **tol)
+        src = torch.randn(50, 96).to(dtype)
+        idx = torch.tensor([3, 3, 49, 0, 7], dtype=torch.int32)
+        assert torch.equal(ops.gather_rows(src.cuda(), idx.cuda()).cpu(), src[idx.long()])
+        lg = torch.randn(4, 1000).to(dtype)
+        pr = ops.softmax_rows(lg.cuda(), 0.8).cpu()
+        assert torch.allclose(pr, torch.softmax(lg.float() / 0.8, dim=-1), atol=1e-6, rtol=1e-4)
