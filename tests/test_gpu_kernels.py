@@ -22,8 +22,18 @@ def lib():
     return cabi.load_library()
 
 
+_KEEP = []
+
+
 def dev(x, dtype=torch.int32):
-    return torch.as_tensor(x, dtype=dtype).cuda()
+    """device tensor kept alive until the end of the test session: a temporary passed as a raw pointer
+    must not be recycled by the caching allocator before the kernel that reads it has run."""
+    t = torch.as_tensor(x, dtype=dtype).cuda()
+    _KEEP.append(t)
+    if len(_KEEP) > 4096:
+        torch.cuda.synchronize()
+        del _KEEP[:2048]
+    return t
 
 
 def load(name):
@@ -246,7 +256,7 @@ def test_pool_kats_bit_exact(lib):
                 win = torch.zeros(N - 1, wcap, dtype=torch.int32)
                 for l, lv in enumerate(op["past"]):
                     win[l, :len(lv)] = torch.tensor(lv, dtype=torch.int32)
-                call("lade_pool_insert_window", ptr(pool_tok), ptr(pool_cnt), V, G, gs, ptr(dev([op["lst"]])), ptr(win.cuda()), wcap,
+                call("lade_pool_insert_window", ptr(pool_tok), ptr(pool_cnt), V, G, gs, ptr(dev([op["lst"]])), ptr(dev(win)), wcap,
                      ptr(dev(op["new"])), W, N)
             elif op["op"] == "prompt":
                 if len(op["prompts"]) > 0:
