@@ -1,0 +1,230 @@
+#!/usr/bin/env python
+"""Benchmark of the lookahead-decoding hot path on MI355X.
+
+Metric (BASELINE.json): tokens/s + step-compression of greedy lookahead decoding on a synthetic
+random-weight Llama-2-7B-shaped model in bf16, W=15 N=5 G=15 (BASELINE config 2), 1/2/4/8 GPUs.
+
+A "step" is one decode step of the lookahead loop = one model forward over T=(N-1)(W+g) tokens
+through the HIP hot path (input assembly, RoPE+KV append, lookahead attention, argmax, verify, pool
+insert, window roll, KV commit) with the weights, KV cache, window and n-gram pool resident in HBM.
+The prompt prefill and the N-2 window-fill steps are setup and are not timed; W warm-up steps and
+exactly K timed steps follow, bracketed by barrier + torch.cuda.synchronize().
+
+    python bench.py --gpus 1 --steps 32 --warmup 8
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+With N > 1 the step runs lookahead-parallel (window columns + candidates sharded over the ranks, one
+RCCL all-gather of a small int32 record per step; lade/decoding.py:973-986, 1088-1107): total work
+per step is fixed, so scaling is "strong".
+
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (the attention kernel,
+algorithmic bytes / live hipEvent timing) and `cpu_baseline` (the CPU oracle = a port of the
+reference's greedy path, timed on this box's host cores on a bounded layer-sliced sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--model", default="llama2-7b")
+    ap.add_argument("--layers", type=int, default=0, help="override the layer count (debug only; invalidates the metric)")
+    ap.add_argument("--window", type=int, default=15)
+    ap.add_argument("--level", type=int, default=5)
+    ap.add_argument("--guess", type=int, default=15)
+    ap.add_argument("--prompt-len", type=int, default=2048)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--no-graph", action="store_true", help="run steady steps eagerly instead of replaying the captured hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-steps", type=int, default=3)
+    return ap.parse_args()
+
+
+def attn_algorithmic_bytes(cfg, T, P, elem=2):
+    """K1 bytes per layer = e*[2*Hkv*(P+T)*d (K,V read) + H*T*d (Q read) + H*T*d (O write)]"""
+    H, Hkv, d = cfg["heads"], cfg["kv_heads"], cfg["head_dim"]
+    return elem * (2 * Hkv * (P + T) * d + 2 * H * T * d)
+
+
+def host_cores() -> int:
+    """cores this process may actually use: the cgroup CPU quota when there is one, else the affinity mask"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(args, cfg_full):
+    """The reference's CPU greedy path cannot travel to this box; its port (oracle/lade_oracle.py, pinned
+    to reference-generated traces) is timed instead, fp32, all host cores, on a bounded sample: a
+    layer-sliced model of the same widths, short prompt, a few steady steps; the per-layer time is
+    extrapolated to the full depth."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import lade_oracle as O
+    from lookaheaddecoding_amd.weights import make_config, weight_shapes
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    W, N, G = args.window, args.level, args.guess
+    prompt_len = 64
+    times = {}
+    for Ls in (1, 2):
+        cfg = make_config(cfg_full, layers=Ls, max_pos=1024)
+        g = torch.Generator().manual_seed(0)
+        w = {}
+        for k, shp in weight_shapes(cfg).items():
+            w[k] = torch.ones(shp) if len(shp) == 1 else torch.empty(shp).normal_(0, 0.02, generator=g)
+        model = O.OracleLlama(cfg, w)
+        prompt = torch.randint(3, cfg["vocab"], (prompt_len,), generator=torch.Generator().manual_seed(123)).tolist()
+        n_steps = (N - 1) + args.cpu_baseline_steps
+        # time whole steps of the oracle loop; the last `cpu_baseline_steps` are steady steps
+        t_marks = []
+        orig = O.model_step
+
+        def timed_step(*a, **k):
+            t0 = time.time()
+            r = orig(*a, **k)
+            t_marks.append((time.time() - t0, r.layout.T))
+            return r
+
+        O.model_step = timed_step
+        try:
+            res = O.lookahead_greedy(model, prompt, W, N, G, prompt_len + n_steps, random.Random(1), keep_trace=False)
+        finally:
+            O.model_step = orig
+        steady = t_marks[N - 1:]
+        times[Ls] = (sum(t for t, _ in steady) / max(1, len(steady)), sum(T for _, T in steady) / max(1, len(steady)), res.steps)
+        del model, w
+    per_layer = max(times[2][0] - times[1][0], 1e-9)
+    fixed = max(times[1][0] - per_layer, 0.0)
+    step_s = fixed + cfg_full["layers"] * per_layer
+    return {"value": round(1.0 / step_s, 4), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/lade_oracle.py (port of lade/decoding.py:697-1259 + modeling_llama.py eager path), fp32, {cores} threads; "
+                      f"layer-sliced {args.model} shape (1 and 2 layers -> per-layer {per_layer * 1e3:.1f} ms, fixed {fixed * 1e3:.1f} ms, "
+                      f"extrapolated to {cfg_full['layers']} layers = {step_s:.2f} s/step), prompt {prompt_len}, {args.cpu_baseline_steps} steady steps, "
+                      f"W={W} N={N} G={G}, T~{times[2][1]:.0f} tokens/step, S=1.0 (cold regime: 1 token/step)",
+            "s_per_step": round(step_s, 4)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from lookaheaddecoding_amd import ops
+    from lookaheaddecoding_amd.decoding import LookaheadDecoder
+    from lookaheaddecoding_amd.engine import StepEngine
+    from lookaheaddecoding_amd.weights import make_config, random_weights_torch
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    cfg = make_config(args.model)
+    if args.layers:
+        cfg["layers"] = args.layers
+    W, N, G = args.window, args.level, args.guess
+    gs = N - 1
+    total_steps = (N - 1) + args.warmup + args.steps + 2
+    max_seq = args.prompt_len + total_steps * N + (N - 1) * (W + G) + 64
+    cfg["max_pos"] = max(cfg.get("max_pos", 4096), max_seq)
+    weights = random_weights_torch(cfg, seed=0, dtype=dtype, device=dev)
+    eng = StepEngine(cfg, weights, dtype=dtype, device=dev, max_seq=max_seq, max_T=512)
+    del weights
+    lp = None
+    if world > 1:
+        from lookaheaddecoding_amd.parallel import LPContext
+        lp = LPContext(rank=rank, world=world)
+    dec = LookaheadDecoder(eng, W, N, G, lp=lp, use_graph=not args.no_graph and world == 1)
+    prompt = torch.randint(3, cfg["vocab"], (args.prompt_len,), generator=torch.Generator().manual_seed(123)).tolist()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    dec.start(prompt, rng=random.Random(1))
+    for _ in range(N - 1):                       # prefill + window fill: setup, untimed
+        dec.step()
+    for _ in range(args.warmup):
+        dec.step()
+    sync()
+    tok0 = len(dec.tokens)
+    t0 = time.perf_counter()
+    infos = []
+    for _ in range(args.steps):
+        infos.append(dec.step())
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    new_tokens = len(dec.tokens) - tok0
+    S = new_tokens / args.steps
+    avg_T = sum(i["T"] for i in infos) / len(infos)
+    P_end = dec.P
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant hand-written kernel: lookahead attention, one layer ----
+        T_mid = int(round(avg_T))
+        g_mid = max(0, (T_mid - (N - 1) * W) // gs)
+        T_k = (N - 1) * W + g_mid * gs
+        mask = ops.StepMask.from_levels(1, [W - 1] + [W] * (N - 2), g_mid * gs, gs, P_end)
+        qkv = torch.randn(T_k, (cfg["heads"] + 2 * cfg["kv_heads"]) * cfg["head_dim"], device=dev).to(dtype)
+        ns = eng.n_splits_for(T_k, P_end + T_k)
+        us = ops.time_attn(qkv, eng.k_cache(0), eng.vt_cache(0), mask, H=cfg["heads"], Hkv=cfg["kv_heads"], d=cfg["head_dim"],
+                           n_splits=ns, reps=200)
+        alg = attn_algorithmic_bytes(cfg, T_k, P_end)
+        achieved = alg / (us * 1e-6) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
+                    "traffic": None, "kernel": f"lade::attn_fwd_kernel<{args.dtype},{cfg['head_dim']}> (+combine, n_splits={ns})",
+                    "launch_us": round(us, 2), "algorithmic_bytes": alg, "T": T_k, "P": P_end,
+                    "note": "one layer's launch pair (attention + split combine) timed with hipEvents on the launch stream (lade_time_attn, 200 reps) at the end-of-run shape"}
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(args, cfg)
+        out = {
+            "metric": "tokens/s, greedy lookahead decoding (W=15,N=5,G=15)" if (W, N, G) == (15, 5, 15) else f"tokens/s, greedy lookahead decoding (W={W},N={N},G={G})",
+            "value": round(new_tokens / elapsed, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (random-init weights, random prompt ids)",
+            "config": {"workload": f"{args.model}-shape ({cfg['layers']}L) {args.dtype} greedy lookahead, 1 sequence, prompt {args.prompt_len}, "
+                                   f"W={W} N={N} G={G}, cold regime (untied random weights)", "parallelism": f"lp{world}" if world > 1 else "single",
+                       "tokens_per_step_T": round(avg_T, 1), "kv_len_end": P_end, "hipgraph": bool(dec.use_graph)},
+            "step_compression": round(S, 3), "steps_per_s": round(args.steps / elapsed, 2),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -108,8 +108,8 @@ typedef struct lade_attn_args {
     const void* k_cache;    /* [Hkv][S_max][d]   keys, row-major            */
     const void* vt_cache;   /* [Hkv][d][S_max]   values, TRANSPOSED (key index fastest) */
     void* out;              /* [T][H][d], token stride out_row_stride */
-    float* part_o;          /* split-KV partials [n_splits][H][T][d] fp32 (n_splits>1) */
-    float* part_ml;         /* [n_splits][H][T][2]  (running max, running sum) */
+    void* part_o;           /* split-KV partial outputs [n_splits][T][H][d], model dtype (n_splits>1) */
+    float* part_ml;         /* [n_splits][H][T][2]  (running max in log2 units, running sum) */
     const int32_t* dyn_P;   /* optional device int32: overrides mask.P at run time (graph replay) */
     int64_t q_row_stride, out_row_stride; /* in elements */
     int32_t H, Hkv, d, S_max;

@@ -18,6 +18,8 @@
 // O^T is lane-local, and the P^T B-operand is taken straight from the S^T accumulators (the k-index
 // permutation this implies is applied to the V^T A-operand addresses instead of shuffling data).
 // V is kept TRANSPOSED in HBM ([Hkv][d][S_max]) so its fragments are contiguous along keys.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace lade {
@@ -30,19 +32,21 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int KT = 64;        // keys per tile
 constexpr int ROWS_PER_WG = 128;
-constexpr float NEG_BIG = -1.0e30f;
+constexpr float NEG_BIG = -1.0e30f;     // initial running max
+constexpr float MASKED = -3.0e30f;      // masked score: 2^(MASKED - m) == 0 even while m is still NEG_BIG
 
 struct AttnK {
     const uint16_t* q;
     const uint16_t* k;
     const uint16_t* vt;
     uint16_t* out;
-    float* part_o;
-    float* part_ml;
+    uint16_t* part_o;     // [n_splits][T][H][D] normalised partial outputs, model dtype
+    float* part_ml;       // [n_splits][H][T][2] (running max in log2 units, running sum)
     const int32_t* dyn_P;
     int64_t q_row_stride, out_row_stride;
     int H, Hkv, S_max, n_splits;
     float scale_log2;   // scale * log2(e)
+    int dbg;
     lade_mask_params m;
 };
 
@@ -112,20 +116,24 @@ __global__ void mask_render_kernel(lade_mask_params m, uint8_t* out) {
     }
 }
 
-// ---- LDS addressing (XOR swizzles keep ds_read_b128 / ds_read_b64 conflict-free) ---------
-// K tile [KT keys][D]: 16-byte chunk c16 of row `row`.
-template <int D>
-__device__ __forceinline__ int k_lds_off(int row, int c16) {
-    constexpr int CPR = D / 8;                       // 16-B chunks per row
-    constexpr int ROWS_PER_BANKROW = 256 / (2 * D) > 0 ? 256 / (2 * D) : 1;
-    const int swz = (row / ROWS_PER_BANKROW) & (CPR - 1);
-    return row * (2 * D) + ((c16 ^ swz) << 4);
+// ---- LDS tiles ------------------------------------------------------------------------------
+// K tile [KT keys][D] and V^T tile [D][KT keys] are filled by LDS-DMA (global_load_lds, 16 B per
+// lane, no VGPR staging).  The DMA writes LDS linearly (wave-uniform base + lane*16), so the XOR
+// swizzle that keeps the ds_read_b128 fragment reads conflict-free is applied to the per-lane
+// SOURCE address and to the read address (never to the destination).
+template <int ROW_BYTES>
+__device__ __forceinline__ int swz16(int row) {          // 16-B chunk swizzle of a row-major tile
+    constexpr int CPR = ROW_BYTES / 16;                  // chunks per row
+    constexpr int RPB = 256 / ROW_BYTES > 0 ? 256 / ROW_BYTES : 1;   // rows per 256-B bank row
+    return (row / RPB) & (CPR - 1);
 }
-// V^T tile [D][KT keys]: 8-byte chunk c8 (4 keys) of row `row`; rows are 128 B.
-__device__ __forceinline__ int vt_lds_off(int row, int c8) {
-    const int swz = (row >> 1) & 15;
-    return row * (2 * KT) + ((c8 ^ swz) << 3);
-}
+template <int ROW_BYTES>
+__device__ __forceinline__ int tile_off(int row, int c16) { return row * ROW_BYTES + ((c16 ^ swz16<ROW_BYTES>(row)) << 4); }
+
+// MFMA row index rho (0..31) of an S^T sub-tile <-> key kappa within the sub-tile.  With
+// kappa = (rho&3) | ((rho>>3)&3)<<2 | ((rho>>2)&1)<<4 the 16 S^T values a lane holds are the 16
+// CONTIGUOUS keys 16*hi .. 16*hi+15, so each PV k-step needs 8 contiguous keys of V^T = one 16-B read.
+__device__ __forceinline__ int kappa(int rho) { return (rho & 3) | (((rho >> 3) & 3) << 2) | (((rho >> 2) & 1) << 4); }
 
 template <typename T> struct Mfma;
 template <> struct Mfma<BF16> {
@@ -139,22 +147,59 @@ template <> struct Mfma<F16> {
     }
 };
 
-template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnK a) {
-    constexpr int KCH = D / 8;            // 16-B chunks per K row
-    constexpr int K_CHUNKS = KT * KCH;    // per tile
-    constexpr int V_CHUNKS = D * (KT / 8);
-    constexpr int K_PER_THR = K_CHUNKS / 256;
-    constexpr int V_PER_THR = V_CHUNKS / 256;
-    constexpr int KSTEPS = D / 16;        // MFMA k-steps of S^T
-    constexpr int DBLK = D / 32;          // 32-row blocks of O^T
+constexpr int NSTAGE = 3;              // LDS ring depth: a work-group's first 3 tiles are requested at once
+constexpr float RESCALE_THR = 8.0f;    // log2 units: the running max is only raised when it grows by more
+constexpr int NTHREADS = 512;          // 8 waves: 4 row groups x 2 key halves, two waves per SIMD
 
+// optional in-kernel timeline (build with -DLADE_ATTN_TIMELINE, run with LADE_ATTN_DBG=16): thread 0 of every
+// work-group stamps s_memtime at 7 points into the words that follow part_ml
+#ifdef LADE_ATTN_TIMELINE
+__device__ __forceinline__ void dbg_stamp(const AttnK& a, int slot) {
+    if ((a.dbg & 16) && threadIdx.x == 0) {
+        const size_t base = (size_t)a.n_splits * a.H * a.m.T * 2;
+        const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        unsigned long long tnow = __builtin_readcyclecounter();
+        reinterpret_cast<unsigned long long*>(a.part_ml + base)[(size_t)wg * 8 + slot] = tnow;
+    }
+}
+#else
+__device__ __forceinline__ void dbg_stamp(const AttnK&, int) {}
+#endif
+
+// Work-group barrier that the compiler cannot move memory operations across.  The raw
+// __builtin_amdgcn_s_barrier() is IntrNoMem: LDS reads that follow it in the source may be scheduled
+// BEFORE it (observed: Q fragments read ahead of the barrier that publishes other waves' LDS-DMA).
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Work split inside a work-group: wave w owns query rows [32*rg, 32*rg+32) of the block and the
+// 32-key sub-tile `kh` of every 64-key tile.  rg = 2*(w>>2) + (w&1), kh = (w>>1)&1: waves w and w+4
+// share a SIMD (dispatch order 0,2,1,3,0,2,1,3), so with T <= 64 (only row groups 0,1 populated) the
+// four busy waves still sit on four different SIMDs, and with more rows every SIMD interleaves two
+// waves - one in its MFMA phase while the other waits on LDS or runs the softmax VALU work.
+// The two key halves keep separate online-softmax states and are merged through LDS at the end.
+template <typename T, int D>
+__global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(AttnK a) {
+    constexpr int KSTEPS = D / 16;                 // MFMA k-steps of S^T
+    constexpr int DBLK = D / 32;                   // 32-row blocks of O^T
+    constexpr int K_BYTES = KT * D * 2, V_BYTES = D * KT * 2, STAGE_BYTES = K_BYTES + V_BYTES;
+    constexpr int Q_BYTES = ROWS_PER_WG * D * 2;
+    constexpr int K_PIECES = K_BYTES / 1024 / 8;   // 1-KiB DMA pieces per wave per tile
+    constexpr int V_PIECES = V_BYTES / 1024 / 8;
+    constexpr int Q_PIECES = Q_BYTES / 1024 / 8;
+    constexpr int PIECES = K_PIECES + V_PIECES;
+    constexpr int K_CPR = D / 8;                   // 16-B chunks per K (and Q) row
+
+    // LDS: [ring of NSTAGE (K tile | V^T tile)] [Q tile]; the ring is reused for the merge + store staging
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* k_lds = smem;
-    unsigned char* vt_lds = smem + KT * D * 2;
+    unsigned char* q_lds = smem + NSTAGE * STAGE_BYTES;
+    dbg_stamp(a, 0);
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rg = ((wave >> 2) << 1) | (wave & 1), kh = (wave >> 1) & 1;
     const int ql = lane & 31, hi = lane >> 5;
     const int kvh = blockIdx.y, sp = blockIdx.z;
     const int n_rep = a.H / a.Hkv;
@@ -165,217 +210,318 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnK a) {
     const int n_tiles = (S_tot + KT - 1) / KT;
     const int tps = (n_tiles + a.n_splits - 1) / a.n_splits;
     const int tile0 = sp * tps;
-    const int tile1 = min(tile0 + tps, n_tiles);
+    const int nt = max(0, min(tile0 + tps, n_tiles) - tile0);
+    const int n_rows = n_rep * m.T;
+    const float invT = 1.0f / (float)m.T;
+    // row r of the (head-in-group, token) row space -> (hg, t); exact for r < 4096, T <= 512
+    auto split_row = [&](int r, int& hg, int& t) {
+        if (n_rep == 1) { hg = 0; t = r; }
+        else { hg = (int)(((float)r + 0.5f) * invT); t = r - hg * m.T; }
+    };
 
-    // this lane's query row
-    const int r = blockIdx.x * ROWS_PER_WG + wave * 32 + ql;
-    const bool valid = r < n_rep * m.T;
-    const int hg = valid ? r / m.T : 0;
-    const int t = valid ? r - hg * m.T : 0;
+    const uint16_t* kbase = a.k + (size_t)kvh * a.S_max * D;
+    const uint16_t* vbase = a.vt + (size_t)kvh * D * a.S_max;
+
+    // ---- LDS-DMA: Q tile once, then K / V^T tiles; every wave moves its share of 1-KiB pieces ----
+#pragma unroll
+    for (int i = 0; i < Q_PIECES; ++i) {
+        const int piece = wave * Q_PIECES + i;
+        const int row = piece * (64 / K_CPR) + lane / K_CPR;
+        const int c = (lane % K_CPR) ^ swz16<2 * D>(row);
+        int r = blockIdx.x * ROWS_PER_WG + row, hg, t;
+        if (r >= n_rows) r = 0;                       // rows past the end read row 0; never stored
+        split_row(r, hg, t);
+        const uint16_t* src = a.q + (size_t)t * a.q_row_stride + (size_t)(kvh * n_rep + hg) * D + c * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(q_lds + piece * 1024), 16, 0, 0);
+    }
+    auto issue_tile = [&](int tile, int stage) {
+        const int k0 = tile * KT;
+        unsigned char* ks = smem + stage * STAGE_BYTES;
+        unsigned char* vs = ks + K_BYTES;
+#pragma unroll
+        for (int i = 0; i < K_PIECES; ++i) {
+            const int piece = wave * K_PIECES + i;
+            const int row = piece * (64 / K_CPR) + lane / K_CPR;
+            const int c = (lane % K_CPR) ^ swz16<2 * D>(row);
+            const uint16_t* src = kbase + (size_t)(k0 + row) * D + c * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(ks + piece * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < V_PIECES; ++i) {
+            const int piece = wave * V_PIECES + i;
+            const int row = piece * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ swz16<2 * KT>(row);
+            const uint16_t* src = vbase + (size_t)row * a.S_max + k0 + c * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(vs + piece * 1024), 16, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < NSTAGE; ++s)
+        if (s < nt) issue_tile(tile0 + s, s);
+    dbg_stamp(a, 1);
+
+    // this lane's query row (overlaps the DMA flight)
+    const int r = blockIdx.x * ROWS_PER_WG + rg * 32 + ql;
+    const bool valid = r < n_rows;
+    int hg = 0, t = 0;
+    if (valid) split_row(r, hg, t);
     const int qh = kvh * n_rep + hg;
     const RowDesc rd = make_row(t, valid, m);
+    const bool wave_rows = __builtin_amdgcn_ballot_w64(valid) != 0ull;     // any row in this wave's group
 
-    // Q^T B-operand fragments: Q[t][qh][kk*16 + hi*8 .. +8]
     u32x4 qf[KSTEPS];
-    {
-        const uint16_t* qp = a.q + (size_t)t * a.q_row_stride + (size_t)qh * D + hi * 8;
-#pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) {
-            if (valid) qf[kk] = *reinterpret_cast<const u32x4*>(qp + kk * 16);
-            else qf[kk] = u32x4{0, 0, 0, 0};
-        }
-    }
-
     f32x16 oacc[DBLK];
 #pragma unroll
     for (int i = 0; i < DBLK; ++i)
 #pragma unroll
         for (int j = 0; j < 16; ++j) oacc[i][j] = 0.f;
     float m_run = NEG_BIG, l_run = 0.f;
+    const int krow = 32 * kh + kappa(ql);          // LDS row (key within the tile) of this lane's MFMA row
 
-    const uint16_t* kbase = a.k + (size_t)kvh * a.S_max * D;
-    const uint16_t* vbase = a.vt + (size_t)kvh * D * a.S_max;
-
-    u32x4 kreg[K_PER_THR], vreg[V_PER_THR];
-    auto load_tile = [&](int tile) {
-        const int k0 = tile * KT;
+    for (int i = 0; i < nt; ++i) {
+        const int stage = i % NSTAGE;
+        const unsigned char* ks = smem + stage * STAGE_BYTES;
+        const unsigned char* vs = ks + K_BYTES;
+        // wait for tile i (and, the first time, the older Q pieces): the pieces of the (up to 2) younger
+        // tiles stay in flight
+        const int younger = min(nt, i + NSTAGE) - (i + 1);
+        if (younger >= 2) wait_vm<2 * PIECES>();
+        else if (younger == 1) wait_vm<PIECES>();
+        else wait_vm<0>();
+        wg_barrier();
+        if (i == 0) {
+            dbg_stamp(a, 2);
+            // Q^T B-operand fragments: Q[row][kk*16 + hi*8 .. +8]
 #pragma unroll
-        for (int i = 0; i < K_PER_THR; ++i) {
-            const int ch = tid + i * 256;
-            const int row = ch / KCH, c16 = ch % KCH;
-            kreg[i] = *reinterpret_cast<const u32x4*>(kbase + (size_t)(k0 + row) * D + c16 * 8);
+            for (int kk = 0; kk < KSTEPS; ++kk)
+                qf[kk] = *reinterpret_cast<const u32x4*>(q_lds + tile_off<2 * D>(rg * 32 + ql, kk * 2 + hi));
         }
+
+        const int k0 = (tile0 + i) * KT;
+        if (k0 + KT > S_tot) {
+            // last tile: V^T columns of keys >= P+T hold stale bytes; zero them (0 * NaN would poison O)
+            unsigned char* vw = smem + stage * STAGE_BYTES + K_BYTES;
+            const int first = S_tot - k0;
+            for (int idx = tid; idx < D * (KT - first); idx += NTHREADS) {
+                const int row = idx / (KT - first), key = first + idx % (KT - first);
+                *reinterpret_cast<uint16_t*>(vw + tile_off<2 * KT>(row, key >> 3) + (key & 7) * 2) = 0;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wg_barrier();
+        }
+        const bool full = (k0 + KT <= m.P);           // whole tile in the cache: every key visible
+        uint32_t bits = 0xffffu;                      // visibility of this lane's 16 keys 32kh + 16hi + e
+        if (!full) bits = (uint32_t)(vis_bits(k0 - m.P, rd, m) >> (32 * kh + 16 * hi)) & 0xffffu;
+        else if (!valid) bits = 0u;
+        if (wave_rows && __builtin_amdgcn_ballot_w64(bits != 0u) != 0ull) {
+            // ---- S^T = K Q^T on this wave's 32-key sub-tile ----
+            f32x16 sacc;
 #pragma unroll
-        for (int i = 0; i < V_PER_THR; ++i) {
-            const int ch = tid + i * 256;
-            const int row = ch / (KT / 8), c = ch % (KT / 8);
-            u32x4 v = *reinterpret_cast<const u32x4*>(vbase + (size_t)row * a.S_max + k0 + c * 8);
-            // keys >= P+T hold stale bytes: zero them so 0 * garbage can never make a NaN
-            const int kfirst = k0 + c * 8;
-            if (kfirst + 8 > S_tot) {
+            for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+            {
+                u32x4 kf[KSTEPS];                   // all fragments first: LDS latency overlaps the MFMAs
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    uint32_t w = v[e];
-                    if (kfirst + 2 * e >= S_tot) w &= 0xffff0000u;
-                    if (kfirst + 2 * e + 1 >= S_tot) w &= 0x0000ffffu;
-                    v[e] = w;
+                for (int kk = 0; kk < KSTEPS; ++kk) kf[kk] = *reinterpret_cast<const u32x4*>(ks + tile_off<2 * D>(krow, kk * 2 + hi));
+#pragma unroll
+                for (int kk = 0; kk < KSTEPS; ++kk) sacc = Mfma<T>::run(kf[kk], qf[kk], sacc);
+            }
+            // V^T fragments of the first PV k-step are requested before the softmax VALU work
+            u32x4 vf0[DBLK];
+#pragma unroll
+            for (int db = 0; db < DBLK; ++db) vf0[db] = *reinterpret_cast<const u32x4*>(vs + tile_off<2 * KT>(db * 32 + ql, 4 * kh + 2 * hi));
+            // ---- online softmax in the log2 domain; lane (q, hi) holds keys 32kh + 16hi + e ----
+            float tmax = NEG_BIG;
+            if (full) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    sacc[e] *= a.scale_log2;
+                    tmax = fmaxf(tmax, sacc[e]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float sv = ((bits >> e) & 1u) ? sacc[e] * a.scale_log2 : MASKED;
+                    sacc[e] = sv;
+                    tmax = fmaxf(tmax, sv);
                 }
             }
-            vreg[i] = v;
-        }
-    };
-    auto store_tile = [&]() {
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            // raise the running max only when it grows by more than RESCALE_THR (wave-uniform decision):
+            // p stays <= 2^THR, harmless in the fp32 accumulators, and the O^T rescale is skipped on most tiles
+            if (__builtin_amdgcn_ballot_w64(tmax > m_run + RESCALE_THR) != 0ull) {
+                const float m_new = fmaxf(m_run, tmax);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                m_run = m_new;
+                l_run *= alpha;
 #pragma unroll
-        for (int i = 0; i < K_PER_THR; ++i) {
-            const int ch = tid + i * 256;
-            const int row = ch / KCH, c16 = ch % KCH;
-            *reinterpret_cast<u32x4*>(k_lds + k_lds_off<D>(row, c16)) = kreg[i];
-        }
+                for (int ii = 0; ii < DBLK; ++ii)
 #pragma unroll
-        for (int i = 0; i < V_PER_THR; ++i) {
-            const int ch = tid + i * 256;
-            const int row = ch / (KT / 8), c = ch % (KT / 8);
-            *reinterpret_cast<u32x2*>(vt_lds + vt_lds_off(row, 2 * c)) = u32x2{vreg[i][0], vreg[i][1]};
-            *reinterpret_cast<u32x2*>(vt_lds + vt_lds_off(row, 2 * c + 1)) = u32x2{vreg[i][2], vreg[i][3]};
-        }
-    };
-
-    if (tile0 < tile1) load_tile(tile0);
-    for (int tile = tile0; tile < tile1; ++tile) {
-        __syncthreads();          // previous tile's LDS reads are done
-        store_tile();
-        __syncthreads();
-        if (tile + 1 < tile1) load_tile(tile + 1);   // in flight while this tile is computed
-
-        const int k0 = tile * KT;
-        const bool full = (k0 + KT <= m.P);           // whole tile in the cache: every key visible
-        uint64_t vis = ~0ull;
-        if (!full) vis = vis_bits(k0 - m.P, rd, m);
-        else if (!valid) vis = 0ull;
-        if (__builtin_amdgcn_ballot_w64(vis != 0ull) == 0ull) continue;   // nothing for this wave here
-
-        // ---- S^T = K Q^T : two 32-key sub-tiles ----
-        f32x16 sacc[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) sacc[j][e] = 0.f;
-#pragma unroll
-            for (int kk = 0; kk < KSTEPS; ++kk) {
-                const u32x4 kf = *reinterpret_cast<const u32x4*>(k_lds + k_lds_off<D>(32 * j + ql, kk * 2 + hi));
-                sacc[j] = Mfma<T>::run(kf, qf[kk], sacc[j]);
+                    for (int e = 0; e < 16; ++e) oacc[ii][e] *= alpha;
             }
-        }
-        // ---- online softmax (log2 domain), masked entries contribute exactly 0 ----
-        float tmax = NEG_BIG;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
+            float psum = 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int kb = 32 * j + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                const float s = ((vis >> kb) & 1ull) ? sacc[j][e] * a.scale_log2 : NEG_BIG;
-                sacc[j][e] = s;
-                tmax = fmaxf(tmax, s);
-            }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = exp2f(m_run - m_new);
-        m_run = m_new;
-        float psum = 0.f;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float s = sacc[j][e];
-                const float p = (s > 0.5f * NEG_BIG) ? exp2f(s - m_new) : 0.f;
-                sacc[j][e] = p;
+                const float p = __builtin_amdgcn_exp2f(sacc[e] - m_run);   // masked: 2^(-3e30 - m) = 0
+                sacc[e] = p;
                 psum += p;
             }
-        l_run = l_run * alpha + psum;
+            l_run += psum;
+            // ---- O^T += V^T P^T : k-step jj = keys 32kh + 16hi + 8jj + 0..7 ----
+            u32x4 vf1[DBLK];
 #pragma unroll
-        for (int i = 0; i < DBLK; ++i)
+            for (int db = 0; db < DBLK; ++db) vf1[db] = *reinterpret_cast<const u32x4*>(vs + tile_off<2 * KT>(db * 32 + ql, 4 * kh + 2 * hi + 1));
+            u32x4 pf0, pf1;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
-
-        // ---- O^T += V^T P^T ----
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                u32x4 pf;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) pf[e] = pack2<T>(sacc[j][8 * jj + 2 * e], sacc[j][8 * jj + 2 * e + 1]);
-                const int c8 = 8 * j + 4 * jj + hi;   // keys 32j+16jj+4hi+{0..3}, and +8
-#pragma unroll
-                for (int db = 0; db < DBLK; ++db) {
-                    const int row = db * 32 + ql;
-                    const u32x2 v0 = *reinterpret_cast<const u32x2*>(vt_lds + vt_lds_off(row, c8));
-                    const u32x2 v1 = *reinterpret_cast<const u32x2*>(vt_lds + vt_lds_off(row, c8 + 2));
-                    oacc[db] = Mfma<T>::run(u32x4{v0[0], v0[1], v1[0], v1[1]}, pf, oacc[db]);
-                }
+            for (int e = 0; e < 4; ++e) {
+                pf0[e] = pack2<T>(sacc[2 * e], sacc[2 * e + 1]);
+                pf1[e] = pack2<T>(sacc[8 + 2 * e], sacc[8 + 2 * e + 1]);
             }
+#pragma unroll
+            for (int db = 0; db < DBLK; ++db) oacc[db] = Mfma<T>::run(vf0[db], pf0, oacc[db]);
+#pragma unroll
+            for (int db = 0; db < DBLK; ++db) oacc[db] = Mfma<T>::run(vf1[db], pf1, oacc[db]);
+        }
+        if (i + NSTAGE < nt) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wg_barrier();              // every wave is done reading this stage
+            issue_tile(tile0 + i + NSTAGE, stage);
+        }
     }
+    dbg_stamp(a, 3);
 
-    // ---- epilogue ----
-    l_run += __shfl_xor(l_run, 32);
-    if (!valid) return;
-    if (a.n_splits == 1) {
-        const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-        uint16_t* op = a.out + (size_t)t * a.out_row_stride + (size_t)qh * D;
+    // ---- merge the two key halves: wave (rg, 1) hands its state to wave (rg, 0), lane to lane ----
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    wg_barrier();                      // ring no longer read or written: reuse it
+    constexpr int EX_F4 = DBLK * 4 + 1;                // float4 slots per lane: O^T (16*DBLK floats) + (m, l, -, -)
+    float4* ex = reinterpret_cast<float4*>(smem) + (size_t)rg * EX_F4 * 64;
+    if (kh == 1) {
+#pragma unroll
+        for (int db = 0; db < DBLK; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                ex[(db * 4 + g4) * 64 + lane] = float4{oacc[db][4 * g4], oacc[db][4 * g4 + 1], oacc[db][4 * g4 + 2], oacc[db][4 * g4 + 3]};
+        ex[(DBLK * 4) * 64 + lane] = float4{m_run, l_run, 0.f, 0.f};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wg_barrier();
+    if (kh == 1) return;
+    {
+        const float4 ml1 = ex[(DBLK * 4) * 64 + lane];
+        const float mm = fmaxf(m_run, ml1.x);
+        const float a0 = __builtin_amdgcn_exp2f(m_run - mm), a1 = __builtin_amdgcn_exp2f(ml1.x - mm);
 #pragma unroll
         for (int db = 0; db < DBLK; ++db)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const int d0 = db * 32 + 8 * g4 + 4 * hi;
+                const float4 o1 = ex[(db * 4 + g4) * 64 + lane];
+                oacc[db][4 * g4 + 0] = oacc[db][4 * g4 + 0] * a0 + o1.x * a1;
+                oacc[db][4 * g4 + 1] = oacc[db][4 * g4 + 1] * a0 + o1.y * a1;
+                oacc[db][4 * g4 + 2] = oacc[db][4 * g4 + 2] * a0 + o1.z * a1;
+                oacc[db][4 * g4 + 3] = oacc[db][4 * g4 + 3] * a0 + o1.w * a1;
+            }
+        l_run = l_run * a0 + ml1.y * a1;
+        m_run = mm;
+    }
+
+    // ---- epilogue: normalise, transpose through LDS, store whole 2D-byte rows ----
+    dbg_stamp(a, 4);
+    l_run += __shfl_xor(l_run, 32);
+    constexpr int RS = 2 * D + 16;                     // staging row stride (bytes), 16-B aligned
+    unsigned char* stg = reinterpret_cast<unsigned char*>(ex);      // this wave's exchange slot is free now
+    {
+        const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+#pragma unroll
+        for (int db = 0; db < DBLK; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
                 u32x2 w;
                 w[0] = pack2<T>(oacc[db][4 * g4 + 0] * inv, oacc[db][4 * g4 + 1] * inv);
                 w[1] = pack2<T>(oacc[db][4 * g4 + 2] * inv, oacc[db][4 * g4 + 3] * inv);
-                *reinterpret_cast<u32x2*>(op + d0) = w;
+                *reinterpret_cast<u32x2*>(stg + ql * RS + (db * 32 + 8 * g4 + 4 * hi) * 2) = w;
             }
-    } else {
+    }
+    if (a.n_splits > 1 && valid && hi == 0) {
         const size_t prow = ((size_t)sp * a.H + qh) * m.T + t;
-        float* po = a.part_o + prow * D;
+        *reinterpret_cast<float2*>(a.part_ml + prow * 2) = float2{m_run, l_run};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    constexpr int CPR = 2 * D / 16;                    // 16-B chunks per output row
+    constexpr int RPI = 64 / CPR;                      // rows per store instruction
+    uint16_t* obase = a.n_splits == 1 ? a.out : a.part_o + (size_t)sp * m.T * a.H * D;
+    const int64_t ostride = a.n_splits == 1 ? a.out_row_stride : (int64_t)a.H * D;
 #pragma unroll
-        for (int db = 0; db < DBLK; ++db)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int d0 = db * 32 + 8 * g4 + 4 * hi;
-                *reinterpret_cast<float4*>(po + d0) =
-                    float4{oacc[db][4 * g4 + 0], oacc[db][4 * g4 + 1], oacc[db][4 * g4 + 2], oacc[db][4 * g4 + 3]};
-            }
-        if (hi == 0) {
-            a.part_ml[prow * 2 + 0] = m_run;
-            a.part_ml[prow * 2 + 1] = l_run;
+    for (int it = 0; it < 32 / RPI; ++it) {
+        const int row = it * RPI + lane / CPR, c = lane % CPR;
+        const int rr = blockIdx.x * ROWS_PER_WG + rg * 32 + row;
+        if (rr < n_rows) {
+            int hg2, t2;
+            split_row(rr, hg2, t2);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(stg + row * RS + c * 16);
+            *reinterpret_cast<u32x4*>(obase + (size_t)t2 * ostride + (size_t)(kvh * n_rep + hg2) * D + c * 8) = v;
         }
     }
+    dbg_stamp(a, 5);
+#ifdef LADE_ATTN_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    dbg_stamp(a, 6);
+#endif
 }
 
-// merges split-KV partials: out = sum_s 2^(m_s-m) o_s / sum_s 2^(m_s-m) l_s
+// merges split-KV partials: out = sum_s w_s o_s / sum_s w_s with w_s = l_s 2^(m_s - m); o_s are the
+// normalised per-split outputs in the model dtype.  One thread per 16 bytes (8 values) of one (token, head);
+// the per-split (m, l) pairs are read first so the partial-output loads are independent.
 template <typename T>
-__global__ void attn_combine_kernel(AttnK a, int D) {
-    const int t = blockIdx.x, qh = blockIdx.y;
+__global__ __launch_bounds__(256) void attn_combine_kernel(AttnK a, int D) {
+    const int t = blockIdx.x, qh = blockIdx.y * blockDim.y + threadIdx.y;
     const int Tn = a.m.T;
-    float mx = NEG_BIG;
-    for (int s = 0; s < a.n_splits; ++s) mx = fmaxf(mx, a.part_ml[(((size_t)s * a.H + qh) * Tn + t) * 2]);
-    for (int d0 = threadIdx.x * 4; d0 < D; d0 += blockDim.x * 4) {
-        float4 acc = float4{0.f, 0.f, 0.f, 0.f};
-        float l = 0.f;
-        for (int s = 0; s < a.n_splits; ++s) {
-            const size_t prow = ((size_t)s * a.H + qh) * Tn + t;
-            const float w = exp2f(a.part_ml[prow * 2] - mx);
-            const float ls = a.part_ml[prow * 2 + 1];
-            if (ls > 0.f) {
-                const float4 o = *reinterpret_cast<const float4*>(a.part_o + prow * D + d0);
-                acc.x += w * o.x; acc.y += w * o.y; acc.z += w * o.z; acc.w += w * o.w;
-                l += w * ls;
+    const int ns = a.n_splits;
+    const int d0 = threadIdx.x * 8;
+    const float* ml = a.part_ml + ((size_t)qh * Tn + t) * 2;
+    const size_t ml_stride = (size_t)a.H * Tn * 2;
+    const uint16_t* po = a.part_o + ((size_t)t * a.H + qh) * D + d0;
+    const size_t po_stride = (size_t)Tn * a.H * D;
+    // one pass, 8 splits at a time: all (m, l) and partial-output loads of a group are issued together
+    float mx = NEG_BIG, wsum = 0.f;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < ns; s0 += 8) {
+        float2 v[8];
+        u32x4 o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int s = min(s0 + j, ns - 1);
+            v[j] = *reinterpret_cast<const float2*>(ml + s * ml_stride);
+            o[j] = *reinterpret_cast<const u32x4*>(po + s * po_stride);
+        }
+        float gm = mx;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (s0 + j < ns && v[j].y > 0.f) gm = fmaxf(gm, v[j].x);
+        const float resc = __builtin_amdgcn_exp2f(mx - gm);      // 2^(NEG_BIG - gm) = 0 on the first group
+        mx = gm;
+        wsum *= resc;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] *= resc;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float ws = (s0 + j < ns && v[j].y > 0.f) ? v[j].y * __builtin_amdgcn_exp2f(v[j].x - mx) : 0.f;
+            wsum += ws;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[2 * e] += ws * to_f32<T>((uint16_t)(o[j][e] & 0xffffu));
+                acc[2 * e + 1] += ws * to_f32<T>((uint16_t)(o[j][e] >> 16));
             }
         }
-        const float inv = l > 0.f ? 1.f / l : 0.f;
-        u32x2 wv;
-        wv[0] = pack2<T>(acc.x * inv, acc.y * inv);
-        wv[1] = pack2<T>(acc.z * inv, acc.w * inv);
-        *reinterpret_cast<u32x2*>(a.out + (size_t)t * a.out_row_stride + (size_t)qh * D + d0) = wv;
     }
+    const float inv = wsum > 0.f ? 1.f / wsum : 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] *= inv;
+    u32x4 wv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wv[e] = pack2<T>(acc[2 * e], acc[2 * e + 1]);
+    *reinterpret_cast<u32x4*>(a.out + (size_t)t * a.out_row_stride + (size_t)qh * D + d0) = wv;
 }
 
 // ---- fp32 path: plain VALU kernel (parity / tiny models; not a BASELINE dtype) -------------
@@ -440,7 +586,7 @@ static int validate(const lade_attn_args* a) {
     LADE_REQUIRE(a->mask.T > 0 && a->mask.P >= 0, LADE_E_ARG, "lade_attn: T=%d P=%d", a->mask.T, a->mask.P);
     LADE_REQUIRE(a->S_max % 64 == 0 && a->mask.P + a->mask.T <= a->S_max, LADE_E_ARG,
                  "lade_attn: S_max=%d must be a multiple of 64 and >= P+T=%d", a->S_max, a->mask.P + a->mask.T);
-    LADE_REQUIRE(a->n_splits >= 1, LADE_E_ARG, "lade_attn: n_splits=%d", a->n_splits);
+    LADE_REQUIRE(a->n_splits >= 1 && a->n_splits <= 32, LADE_E_ARG, "lade_attn: n_splits=%d (1..32)", a->n_splits);
     LADE_REQUIRE(a->n_splits == 1 || (a->part_o && a->part_ml), LADE_E_ARG, "lade_attn: split-KV needs partial buffers");
     if (!a->mask.is_prefill) {
         const lade_mask_params& m = a->mask;
@@ -457,10 +603,11 @@ static int validate(const lade_attn_args* a) {
 static AttnK make_k(const lade_attn_args* a) {
     AttnK k;
     k.q = (const uint16_t*)a->q; k.k = (const uint16_t*)a->k_cache; k.vt = (const uint16_t*)a->vt_cache;
-    k.out = (uint16_t*)a->out; k.part_o = a->part_o; k.part_ml = a->part_ml; k.dyn_P = a->dyn_P;
+    k.out = (uint16_t*)a->out; k.part_o = (uint16_t*)a->part_o; k.part_ml = a->part_ml; k.dyn_P = a->dyn_P;
     k.q_row_stride = a->q_row_stride; k.out_row_stride = a->out_row_stride;
     k.H = a->H; k.Hkv = a->Hkv; k.S_max = a->S_max; k.n_splits = a->n_splits;
     k.scale_log2 = a->scale * 1.4426950408889634f;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("LADE_ATTN_DBG"); dbg = e ? atoi(e) : 0; } k.dbg = dbg; }
     k.m = a->mask;
     return k;
 }
@@ -470,8 +617,13 @@ static int launch_fwd(const lade_attn_args* a, hipStream_t st) {
     const AttnK k = make_k(a);
     const int n_rep = a->H / a->Hkv;
     dim3 grid(cdiv(n_rep * a->mask.T, ROWS_PER_WG), a->Hkv, a->n_splits);
-    const size_t lds = (size_t)KT * D * 2 * 2;
-    hipLaunchKernelGGL((attn_fwd_kernel<T, D>), grid, dim3(256), lds, st, k);
+    const size_t lds = (size_t)KT * D * 2 * 2 * NSTAGE + (size_t)ROWS_PER_WG * D * 2;
+    static bool attr_set = false;          // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((attn_fwd_kernel<T, D>), grid, dim3(NTHREADS), lds, st, k);
     return check_launch("lade_attn_fwd");
 }
 
@@ -498,7 +650,7 @@ extern "C" int lade_attn_fwd(const lade_attn_args* a, void* stream) {
     }
     LADE_REQUIRE(a->dtype == LADE_BF16 || a->dtype == LADE_F16, LADE_E_DTYPE, "lade_attn_fwd: dtype=%d", a->dtype);
     LADE_REQUIRE(a->d == 128 || a->d == 64, LADE_E_DTYPE, "lade_attn_fwd: head_dim %d (MFMA kernel supports 64 and 128)", a->d);
-    LADE_REQUIRE(a->q_row_stride % 8 == 0 && a->out_row_stride % 4 == 0, LADE_E_ARG, "lade_attn_fwd: row strides must keep 16-B alignment");
+    LADE_REQUIRE(a->q_row_stride % 8 == 0 && a->out_row_stride % 8 == 0, LADE_E_ARG, "lade_attn_fwd: row strides must keep 16-B alignment");
     if (a->dtype == LADE_BF16) return a->d == 128 ? launch_fwd<BF16, 128>(a, st) : launch_fwd<BF16, 64>(a, st);
     return a->d == 128 ? launch_fwd<F16, 128>(a, st) : launch_fwd<F16, 64>(a, st);
 }
@@ -509,10 +661,12 @@ extern "C" int lade_attn_combine(const lade_attn_args* a, void* stream) {
     LADE_REQUIRE(a->n_splits > 1, LADE_E_ARG, "lade_attn_combine: n_splits=%d", a->n_splits);
     LADE_REQUIRE(a->dtype == LADE_BF16 || a->dtype == LADE_F16, LADE_E_DTYPE, "lade_attn_combine: dtype=%d", a->dtype);
     const AttnK k = make_k(a);
-    dim3 grid(a->mask.T, a->H);
-    const int thr = a->d / 4 < 64 ? 64 : a->d / 4;
-    if (a->dtype == LADE_BF16) hipLaunchKernelGGL(attn_combine_kernel<BF16>, grid, dim3(thr), 0, (hipStream_t)stream, k, a->d);
-    else hipLaunchKernelGGL(attn_combine_kernel<F16>, grid, dim3(thr), 0, (hipStream_t)stream, k, a->d);
+    LADE_REQUIRE(a->n_splits <= 32, LADE_E_LIMIT, "lade_attn_combine: n_splits=%d > 32", a->n_splits);
+    int hpb = 256 / (a->d / 8);                       // heads per block
+    while (hpb > 1 && a->H % hpb != 0) hpb >>= 1;
+    dim3 grid(a->mask.T, a->H / hpb), block(a->d / 8, hpb);
+    if (a->dtype == LADE_BF16) hipLaunchKernelGGL(attn_combine_kernel<BF16>, grid, block, 0, (hipStream_t)stream, k, a->d);
+    else hipLaunchKernelGGL(attn_combine_kernel<F16>, grid, block, 0, (hipStream_t)stream, k, a->d);
     return check_launch("lade_attn_combine");
 }
 

@@ -40,41 +40,100 @@ __device__ __forceinline__ float block_max(float v, float* sm) {
     return t;
 }
 
-// y = w * cast(x_f32 * rsqrt(mean(x^2)+eps));  ADD: x <- cast(x + r) first (residual), norm of the sum
-template <typename T, bool ADD>
+// ---- 16-byte vector access of the storage types --------------------------------------------------
+template <typename T> struct Vec;             // VEC elements per 16 bytes
+template <> struct Vec<BF16> { static constexpr int N = 8; };
+template <> struct Vec<F16> { static constexpr int N = 8; };
+template <> struct Vec<F32> { static constexpr int N = 4; };
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> __device__ __forceinline__ void unpack(const u32x4& v, float* f);
+template <> __device__ __forceinline__ void unpack<BF16>(const u32x4& v, float* f) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f[2 * e] = __uint_as_float(v[e] << 16); f[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u); }
+}
+template <> __device__ __forceinline__ void unpack<F16>(const u32x4& v, float* f) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f[2 * e] = to_f32<F16>((uint16_t)(v[e] & 0xffffu)); f[2 * e + 1] = to_f32<F16>((uint16_t)(v[e] >> 16)); }
+}
+template <> __device__ __forceinline__ void unpack<F32>(const u32x4& v, float* f) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[e] = __uint_as_float(v[e]);
+}
+template <typename T> __device__ __forceinline__ u32x4 repack(const float* f);
+template <> __device__ __forceinline__ u32x4 repack<BF16>(const float* f) {
+    u32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (uint32_t)from_f32<BF16>(f[2 * e]) | ((uint32_t)from_f32<BF16>(f[2 * e + 1]) << 16);
+    return v;
+}
+template <> __device__ __forceinline__ u32x4 repack<F16>(const float* f) {
+    u32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (uint32_t)from_f32<F16>(f[2 * e]) | ((uint32_t)from_f32<F16>(f[2 * e + 1]) << 16);
+    return v;
+}
+template <> __device__ __forceinline__ u32x4 repack<F32>(const float* f) {
+    return u32x4{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
+}
+// value after one rounding to the storage type
+template <typename T> __device__ __forceinline__ float rnd_st(float f) { typename St<T>::S s = stf<T>(f); return ldf<T>(&s, 0); }
+
+// y = w * cast(x_f32 * rsqrt(mean(x^2)+eps));  ADD: x <- cast(x + r) first (residual), norm of the sum.
+// One block per row, the row lives in registers (<= CH 16-byte chunks per thread): one HBM pass.
+template <typename T, bool ADD, int CH>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(typename St<T>::S* x, const typename St<T>::S* r, const typename St<T>::S* w,
                                                       typename St<T>::S* y, int hidden, float eps) {
+    constexpr int N = Vec<T>::N;
     __shared__ float sm[8];
     const size_t base = (size_t)blockIdx.x * hidden;
+    const int nvec = hidden / N;
+    float v[CH][N];
     float ss = 0.f;
-    for (int i = threadIdx.x; i < hidden; i += blockDim.x) {
-        float v = ldf<T>(x, base + i);
-        if (ADD) {
-            v = ldf<T>(&x[0], base + i) + ldf<T>(r, base + i);
-            const typename St<T>::S sv = stf<T>(v);
-            x[base + i] = sv;
-            v = ldf<T>(&sv, 0);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int i = threadIdx.x + c * 256;
+        if (i < nvec) {
+            unpack<T>(*reinterpret_cast<const u32x4*>(x + base + (size_t)i * N), v[c]);
+            if (ADD) {
+                float rr[N];
+                unpack<T>(*reinterpret_cast<const u32x4*>(r + base + (size_t)i * N), rr);
+#pragma unroll
+                for (int e = 0; e < N; ++e) v[c][e] = rnd_st<T>(v[c][e] + rr[e]);
+                *reinterpret_cast<u32x4*>(x + base + (size_t)i * N) = repack<T>(v[c]);
+            }
+#pragma unroll
+            for (int e = 0; e < N; ++e) ss += v[c][e] * v[c][e];
         }
-        ss += v * v;
     }
     const float var = block_sum(ss, sm) / (float)hidden;
     const float inv = rsqrtf(var + eps);
-    for (int i = threadIdx.x; i < hidden; i += blockDim.x) {
-        const float v = ldf<T>(x, base + i);
-        const typename St<T>::S n = stf<T>(v * inv);             // hidden_states.to(input_dtype)
-        y[base + i] = stf<T>(ldf<T>(w, i) * ldf<T>(&n, 0));        // weight * ...
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int i = threadIdx.x + c * 256;
+        if (i < nvec) {
+            float ww[N], o[N];
+            unpack<T>(*reinterpret_cast<const u32x4*>(w + (size_t)i * N), ww);
+#pragma unroll
+            for (int e = 0; e < N; ++e) o[e] = ww[e] * rnd_st<T>(v[c][e] * inv);     // weight * hidden.to(dtype)
+            *reinterpret_cast<u32x4*>(y + base + (size_t)i * N) = repack<T>(o);
+        }
     }
 }
 
 // out[r][i] = silu(gu[r][i]) * gu[r][inter+i], rounded like torch: act(gate) -> dtype, then * up -> dtype
 template <typename T>
 __global__ __launch_bounds__(256) void silu_mul_kernel(const typename St<T>::S* gu, typename St<T>::S* out, int inter) {
+    constexpr int N = Vec<T>::N;
     const size_t rb = (size_t)blockIdx.y * 2 * inter;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) * N;
     if (i >= inter) return;
-    const float g = ldf<T>(gu, rb + i), u = ldf<T>(gu, rb + inter + i);
-    const typename St<T>::S a = stf<T>(g / (1.f + __expf(-g)));
-    out[(size_t)blockIdx.y * inter + i] = stf<T>(ldf<T>(&a, 0) * u);
+    float g[N], u[N], o[N];
+    unpack<T>(*reinterpret_cast<const u32x4*>(gu + rb + i), g);
+    unpack<T>(*reinterpret_cast<const u32x4*>(gu + rb + inter + i), u);
+#pragma unroll
+    for (int e = 0; e < N; ++e) o[e] = rnd_st<T>(g[e] / (1.f + __expf(-g[e]))) * u[e];
+    *reinterpret_cast<u32x4*>(out + (size_t)blockIdx.y * inter + i) = repack<T>(o);
 }
 
 __global__ __launch_bounds__(256) void gather_rows_kernel(const unsigned char* src, const int32_t* idx, unsigned char* dst, int row_bytes, int src_rows) {
@@ -112,6 +171,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const typename St<T>:
 
 using namespace lade;
 
+
 #define DISPATCH_DTYPE(dtype, CALL)                                   \
     switch (dtype) {                                                  \
         case LADE_BF16: { typedef BF16 TT; CALL; } break;             \
@@ -120,29 +180,40 @@ using namespace lade;
         default: LADE_REQUIRE(false, LADE_E_DTYPE, "unsupported dtype %d", dtype); \
     }
 
+template <bool ADD>
+static int launch_rmsnorm(void* x, const void* r, const void* weight, void* y, int rows, int hidden, float eps, int dtype, hipStream_t st) {
+    const int nvec_bytes = dtype == LADE_F32 ? 4 : 8;
+    LADE_REQUIRE(hidden % nvec_bytes == 0, LADE_E_ARG, "lade_rmsnorm: hidden=%d must be a multiple of %d", hidden, nvec_bytes);
+    const int chunks = cdiv(hidden / nvec_bytes, 256);
+    LADE_REQUIRE(chunks <= 8, LADE_E_LIMIT, "lade_rmsnorm: hidden=%d too large for the register-resident row", hidden);
+#define RMS_LAUNCH(CH) DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((rmsnorm_kernel<TT, ADD, CH>), dim3(rows), dim3(256), 0, st, (St<TT>::S*)x, \
+                                      (const St<TT>::S*)r, (const St<TT>::S*)weight, (St<TT>::S*)y, hidden, eps))
+    if (chunks <= 1) { RMS_LAUNCH(1); } else if (chunks <= 2) { RMS_LAUNCH(2); } else if (chunks <= 4) { RMS_LAUNCH(4); } else { RMS_LAUNCH(8); }
+#undef RMS_LAUNCH
+    return check_launch(ADD ? "lade_add_rmsnorm" : "lade_rmsnorm");
+}
+
 extern "C" int lade_rmsnorm(const void* x, const void* weight, void* y, int32_t rows, int32_t hidden, float eps, int32_t dtype, void* stream) {
     LADE_REQUIRE(x && weight && y && rows >= 0 && hidden > 0, LADE_E_ARG, "lade_rmsnorm: rows=%d hidden=%d", rows, hidden);
     if (rows == 0) return LADE_OK;
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((rmsnorm_kernel<TT, false>), dim3(rows), dim3(256), 0, st, (St<TT>::S*)x, (const St<TT>::S*)nullptr,
-                                             (const St<TT>::S*)weight, (St<TT>::S*)y, hidden, eps));
-    return check_launch("lade_rmsnorm");
+    return launch_rmsnorm<false>((void*)x, nullptr, weight, y, rows, hidden, eps, dtype, st);
 }
 
 extern "C" int lade_add_rmsnorm(void* x, const void* r, const void* weight, void* y, int32_t rows, int32_t hidden, float eps, int32_t dtype, void* stream) {
     LADE_REQUIRE(x && r && weight && y && rows >= 0 && hidden > 0, LADE_E_ARG, "lade_add_rmsnorm: rows=%d hidden=%d", rows, hidden);
     if (rows == 0) return LADE_OK;
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((rmsnorm_kernel<TT, true>), dim3(rows), dim3(256), 0, st, (St<TT>::S*)x, (const St<TT>::S*)r,
-                                             (const St<TT>::S*)weight, (St<TT>::S*)y, hidden, eps));
-    return check_launch("lade_add_rmsnorm");
+    return launch_rmsnorm<true>(x, r, weight, y, rows, hidden, eps, dtype, st);
 }
 
 extern "C" int lade_silu_mul(const void* gu, void* out, int32_t rows, int32_t inter, int32_t dtype, void* stream) {
     LADE_REQUIRE(gu && out && rows >= 0 && inter > 0, LADE_E_ARG, "lade_silu_mul: rows=%d inter=%d", rows, inter);
     if (rows == 0) return LADE_OK;
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(silu_mul_kernel<TT>, dim3(cdiv(inter, 256), rows), dim3(256), 0, st, (const St<TT>::S*)gu, (St<TT>::S*)out, inter));
+    LADE_REQUIRE(inter % 8 == 0, LADE_E_ARG, "lade_silu_mul: inter=%d must be a multiple of 8", inter);
+    const int per_thr = dtype == LADE_F32 ? 4 : 8;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(silu_mul_kernel<TT>, dim3(cdiv(inter / per_thr, 256), rows), dim3(256), 0, st, (const St<TT>::S*)gu, (St<TT>::S*)out, inter));
     return check_launch("lade_silu_mul");
 }
 

@@ -7,6 +7,8 @@
 // These kernels move a few hundred bytes; they are latency bound, so each is a single 64-lane
 // workgroup (one wavefront) with the sequential semantics of the reference preserved where it
 // matters: pool inserts with duplicate keys inside one step must happen in column order.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace lade {
@@ -255,27 +257,51 @@ template <> __device__ __forceinline__ float ld_logit<BF16>(const void* p, size_
 template <> __device__ __forceinline__ float ld_logit<F16>(const void* p, size_t i) { return to_f32<F16>(((const uint16_t*)p)[i]); }
 template <> __device__ __forceinline__ float ld_logit<F32>(const void* p, size_t i) { return ((const float*)p)[i]; }
 
+// one block of 1024 threads per row; 16-byte loads when the row is 16-byte aligned
 template <typename T>
-__global__ __launch_bounds__(256) void argmax_rows_kernel(const void* logits, int64_t ld, int V, int32_t* out) {
+__global__ __launch_bounds__(1024) void argmax_rows_kernel(const void* logits, int64_t ld, int V, int32_t* out) {
+    constexpr int ES = sizeof(T) == 0 ? 2 : 2;
     const int row = blockIdx.x;
     const size_t base = (size_t)row * ld;
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = threadIdx.x; i < V; i += 256) {
-        const float v = ld_logit<T>(logits, base + i);
+    auto upd = [&](float v, int i) {
         if (v > best || (v == best && i < bi) || bi == 0x7fffffff) { best = v; bi = i; }
+    };
+    constexpr bool is16 = !__is_same(T, F32);
+    constexpr int VEC = is16 ? 8 : 4;
+    const size_t ebytes = is16 ? 2 : 4;
+    const bool aligned = (((size_t)logits + base * ebytes) & 15) == 0;
+    int vend = 0;
+    if (aligned) {
+        vend = (V / VEC) * VEC;
+        for (int i = threadIdx.x * VEC; i < vend; i += 1024 * VEC) {
+            const uint4 u = *reinterpret_cast<const uint4*>((const char*)logits + (base + i) * ebytes);
+            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+            if (is16) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    upd(to_f32<typename std::conditional<is16, T, BF16>::type>((uint16_t)(w[e] & 0xffffu)), i + 2 * e);
+                    upd(to_f32<typename std::conditional<is16, T, BF16>::type>((uint16_t)(w[e] >> 16)), i + 2 * e + 1);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) upd(__uint_as_float(w[e]), i + e);
+            }
+        }
     }
+    for (int i = vend + threadIdx.x; i < V; i += 1024) upd(ld_logit<T>(logits, base + i), i);
     for (int o = 32; o > 0; o >>= 1) {
         const float ob = __shfl_xor(best, o);
         const int oi = __shfl_xor(bi, o);
         if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
-    __shared__ float sb[4];
-    __shared__ int si[4];
+    __shared__ float sb[16];
+    __shared__ int si[16];
     if ((threadIdx.x & 63) == 0) { sb[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w)
+        for (int w = 1; w < 16; ++w)
             if (sb[w] > best || (sb[w] == best && si[w] < bi)) { best = sb[w]; bi = si[w]; }
         out[row] = bi;
     }
@@ -557,9 +583,9 @@ extern "C" int lade_argmax_rows(const void* logits, int64_t ld, int32_t rows, in
     if (rows == 0) return LADE_OK;
     hipStream_t st = (hipStream_t)stream;
     switch (dtype) {
-        case LADE_BF16: hipLaunchKernelGGL(argmax_rows_kernel<BF16>, dim3(rows), dim3(256), 0, st, logits, ld, V, out); break;
-        case LADE_F16: hipLaunchKernelGGL(argmax_rows_kernel<F16>, dim3(rows), dim3(256), 0, st, logits, ld, V, out); break;
-        case LADE_F32: hipLaunchKernelGGL(argmax_rows_kernel<F32>, dim3(rows), dim3(256), 0, st, logits, ld, V, out); break;
+        case LADE_BF16: hipLaunchKernelGGL(argmax_rows_kernel<BF16>, dim3(rows), dim3(1024), 0, st, logits, ld, V, out); break;
+        case LADE_F16: hipLaunchKernelGGL(argmax_rows_kernel<F16>, dim3(rows), dim3(1024), 0, st, logits, ld, V, out); break;
+        case LADE_F32: hipLaunchKernelGGL(argmax_rows_kernel<F32>, dim3(rows), dim3(1024), 0, st, logits, ld, V, out); break;
         default: LADE_REQUIRE(false, LADE_E_DTYPE, "lade_argmax_rows: dtype=%d", dtype);
     }
     return check_launch("lade_argmax_rows");

@@ -25,63 +25,84 @@ __device__ __forceinline__ float rnd(float f) {
     return r;
 }
 
-// grid: (T tokens); threads loop over (head, i < d/2).  q rotated in place, rotated k -> cache.
+// One launch does both halves of the append.
+//   blocks [0, T)           : token t.  q rotated in place, rotated k -> K cache row P+t.  A thread owns
+//                             VEC consecutive pairs (i, i+d/2) of one head: 16-byte loads / stores.
+//   blocks [T, T + n_vblk)  : V transpose.  Block (kv head, 64-token slab, 32-wide d chunk) stages the
+//                             slab through LDS and writes V^T[d][P+t] with the token index fastest.
 template <typename T>
-__global__ __launch_bounds__(256) void rope_append_kernel(typename Elem<T>::S* qkv, const int32_t* positions,
-                                                          const typename Elem<T>::S* cos_tab,
-                                                          const typename Elem<T>::S* sin_tab,
-                                                          typename Elem<T>::S* k_cache, int P, const int32_t* dyn_P,
-                                                          int H, int Hkv, int d, int S_max, int max_pos) {
+__global__ __launch_bounds__(256) void rope_kv_append_kernel(typename Elem<T>::S* qkv, const int32_t* positions,
+                                                             const typename Elem<T>::S* cos_tab,
+                                                             const typename Elem<T>::S* sin_tab,
+                                                             typename Elem<T>::S* k_cache, typename Elem<T>::S* vt_cache,
+                                                             int T_, int P, const int32_t* dyn_P, int H, int Hkv, int d,
+                                                             int S_max, int max_pos) {
     typedef typename Elem<T>::S S;
-    const int t = blockIdx.x;
+    constexpr int VEC = 16 / sizeof(S);
+    __shared__ S sm[64][32 + 2];
     if (dyn_P) P = *dyn_P;
-    int pos = positions[t];
-    pos = pos < 0 ? 0 : (pos >= max_pos ? max_pos - 1 : pos);
-    const S* c = cos_tab + (size_t)pos * d;
-    const S* s = sin_tab + (size_t)pos * d;
-    const int half = d >> 1;
-    S* row = qkv + (size_t)t * (H + 2 * Hkv) * d;
-    const int n_pairs = (H + Hkv) * half;
-    for (int idx = threadIdx.x; idx < n_pairs; idx += blockDim.x) {
-        const int h = idx / half, i = idx - h * half;
-        S* x = row + (size_t)h * d;
-        const float x1 = Elem<T>::ld(x[i]), x2 = Elem<T>::ld(x[i + half]);
-        const float c1 = Elem<T>::ld(c[i]), c2 = Elem<T>::ld(c[i + half]);
-        const float s1 = Elem<T>::ld(s[i]), s2 = Elem<T>::ld(s[i + half]);
-        // q*cos + rotate_half(q)*sin, rotate_half = cat(-x2, x1)
-        const float o1 = rnd<T>(__fadd_rn(rnd<T>(__fmul_rn(x1, c1)), rnd<T>(__fmul_rn(-x2, s1))));
-        const float o2 = rnd<T>(__fadd_rn(rnd<T>(__fmul_rn(x2, c2)), rnd<T>(__fmul_rn(x1, s2))));
-        if (h < H) {
-            x[i] = Elem<T>::st(o1);
-            x[i + half] = Elem<T>::st(o2);
+    const int row_w = (H + 2 * Hkv) * d;
+    if ((int)blockIdx.x < T_) {
+        const int t = blockIdx.x;
+        int pos = positions[t];
+        pos = pos < 0 ? 0 : (pos >= max_pos ? max_pos - 1 : pos);
+        const S* c = cos_tab + (size_t)pos * d;
+        const S* s = sin_tab + (size_t)pos * d;
+        const int half = d >> 1;
+        S* row = qkv + (size_t)t * row_w;
+        if (half % VEC == 0) {
+            const int vph = half / VEC;                               // vectors per half head
+            for (int idx = threadIdx.x; idx < (H + Hkv) * vph; idx += blockDim.x) {
+                const int h = idx / vph, i = (idx - h * vph) * VEC;
+                S* x = row + (size_t)h * d;
+                S x1[VEC], x2[VEC], c1[VEC], c2[VEC], s1[VEC], s2[VEC], o1[VEC], o2[VEC];
+                *reinterpret_cast<uint4*>(x1) = *reinterpret_cast<const uint4*>(x + i);
+                *reinterpret_cast<uint4*>(x2) = *reinterpret_cast<const uint4*>(x + i + half);
+                *reinterpret_cast<uint4*>(c1) = *reinterpret_cast<const uint4*>(c + i);
+                *reinterpret_cast<uint4*>(c2) = *reinterpret_cast<const uint4*>(c + i + half);
+                *reinterpret_cast<uint4*>(s1) = *reinterpret_cast<const uint4*>(s + i);
+                *reinterpret_cast<uint4*>(s2) = *reinterpret_cast<const uint4*>(s + i + half);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float a1 = Elem<T>::ld(x1[e]), a2 = Elem<T>::ld(x2[e]);
+                    // q*cos + rotate_half(q)*sin, rotate_half = cat(-x2, x1); one rounding per torch op
+                    o1[e] = Elem<T>::st(__fadd_rn(rnd<T>(__fmul_rn(a1, Elem<T>::ld(c1[e]))), rnd<T>(__fmul_rn(-a2, Elem<T>::ld(s1[e])))));
+                    o2[e] = Elem<T>::st(__fadd_rn(rnd<T>(__fmul_rn(a2, Elem<T>::ld(c2[e]))), rnd<T>(__fmul_rn(a1, Elem<T>::ld(s2[e])))));
+                }
+                S* dst = h < H ? x : k_cache + ((size_t)(h - H) * S_max + P + t) * d;
+                *reinterpret_cast<uint4*>(dst + i) = *reinterpret_cast<const uint4*>(o1);
+                *reinterpret_cast<uint4*>(dst + i + half) = *reinterpret_cast<const uint4*>(o2);
+            }
         } else {
-            S* kr = k_cache + ((size_t)(h - H) * S_max + P + t) * d;
-            kr[i] = Elem<T>::st(o1);
-            kr[i + half] = Elem<T>::st(o2);
+            for (int idx = threadIdx.x; idx < (H + Hkv) * half; idx += blockDim.x) {
+                const int h = idx / half, i = idx - h * half;
+                S* x = row + (size_t)h * d;
+                const float a1 = Elem<T>::ld(x[i]), a2 = Elem<T>::ld(x[i + half]);
+                const float o1 = rnd<T>(__fadd_rn(rnd<T>(__fmul_rn(a1, Elem<T>::ld(c[i]))), rnd<T>(__fmul_rn(-a2, Elem<T>::ld(s[i])))));
+                const float o2 = rnd<T>(__fadd_rn(rnd<T>(__fmul_rn(a2, Elem<T>::ld(c[i + half]))), rnd<T>(__fmul_rn(a1, Elem<T>::ld(s[i + half])))));
+                S* dst = h < H ? x : k_cache + ((size_t)(h - H) * S_max + P + t) * d;
+                dst[i] = Elem<T>::st(o1);
+                dst[i + half] = Elem<T>::st(o2);
+            }
         }
+        return;
     }
-}
-
-// grid: (Hkv, ceil(T/64)); transposes 64 tokens x d of V through LDS so the writes run along keys.
-template <typename T>
-__global__ __launch_bounds__(256) void v_append_kernel(const typename Elem<T>::S* qkv, typename Elem<T>::S* vt_cache,
-                                                       int T_, int P, const int32_t* dyn_P, int H, int Hkv, int d,
-                                                       int S_max) {
-    typedef typename Elem<T>::S S;
-    extern __shared__ unsigned char sm_raw[];
-    S* sm = reinterpret_cast<S*>(sm_raw);          // [64][d+1]
-    if (dyn_P) P = *dyn_P;
-    const int kvh = blockIdx.x, t0 = blockIdx.y * 64;
+    // ---- V transpose ----
+    const int dch = (d + 31) / 32;
+    int b = blockIdx.x - T_;
+    const int dc = b % dch; b /= dch;
+    const int kvh = b % Hkv;
+    const int t0 = (b / Hkv) * 64;
     const int nt = min(64, T_ - t0);
-    const int ld = d + 1;
-    for (int idx = threadIdx.x; idx < nt * d; idx += blockDim.x) {
-        const int tt = idx / d, dd = idx - tt * d;
-        sm[tt * ld + dd] = qkv[(size_t)(t0 + tt) * (H + 2 * Hkv) * d + (size_t)(H + Hkv + kvh) * d + dd];
+    const int d0 = dc * 32, nd = min(32, d - d0);
+    for (int idx = threadIdx.x; idx < 64 * 32; idx += blockDim.x) {
+        const int tt = idx >> 5, dd = idx & 31;
+        if (tt < nt && dd < nd) sm[tt][dd] = qkv[(size_t)(t0 + tt) * row_w + (size_t)(H + Hkv + kvh) * d + d0 + dd];
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < 64 * d; idx += blockDim.x) {
+    for (int idx = threadIdx.x; idx < 32 * 64; idx += blockDim.x) {
         const int dd = idx >> 6, tt = idx & 63;
-        if (tt < nt) vt_cache[((size_t)kvh * d + dd) * S_max + P + t0 + tt] = sm[tt * ld + dd];
+        if (tt < nt && dd < nd) vt_cache[((size_t)kvh * d + d0 + dd) * S_max + P + t0 + tt] = sm[tt][dd];
     }
 }
 
@@ -108,13 +129,10 @@ static int launch_rope(void* qkv, const int32_t* positions, const void* cos_tab,
                        void* vt_cache, int T_, int P, const int32_t* dyn_P, int H, int Hkv, int d, int S_max, int max_pos,
                        hipStream_t st) {
     typedef typename Elem<T>::S S;
-    hipLaunchKernelGGL(rope_append_kernel<T>, dim3(T_), dim3(256), 0, st, (S*)qkv, positions, (const S*)cos_tab,
-                       (const S*)sin_tab, (S*)k_cache, P, dyn_P, H, Hkv, d, S_max, max_pos);
-    int rc = check_launch("lade_rope_kv_append(rope)");
-    if (rc) return rc;
-    hipLaunchKernelGGL(v_append_kernel<T>, dim3(Hkv, cdiv(T_, 64)), dim3(256), 64 * (d + 1) * sizeof(S), st, (const S*)qkv,
-                       (S*)vt_cache, T_, P, dyn_P, H, Hkv, d, S_max);
-    return check_launch("lade_rope_kv_append(v)");
+    const int n_vblk = Hkv * cdiv(T_, 64) * cdiv(d, 32);
+    hipLaunchKernelGGL(rope_kv_append_kernel<T>, dim3(T_ + n_vblk), dim3(256), 0, st, (S*)qkv, positions, (const S*)cos_tab,
+                       (const S*)sin_tab, (S*)k_cache, (S*)vt_cache, T_, P, dyn_P, H, Hkv, d, S_max, max_pos);
+    return check_launch("lade_rope_kv_append");
 }
 
 }  // namespace lade

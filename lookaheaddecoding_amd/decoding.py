@@ -84,8 +84,10 @@ class LadeState:
 class LookaheadDecoder:
     """Greedy / sampling lookahead decoding of one sequence on a `StepEngine`."""
 
-    def __init__(self, engine: StepEngine, W: int, N: int, G: int, pool_from_prompt: bool = False, lp=None):
+    def __init__(self, engine: StepEngine, W: int, N: int, G: int, pool_from_prompt: bool = False, lp=None, use_graph: bool = False):
         self.e = engine
+        self.use_graph = bool(use_graph)
+        self._graph = None
         self.W, self.N, self.G, self.gs = W, N, G, N - 1
         self.pool_from_prompt = bool(pool_from_prompt)
         self.lp = lp                      # lookahead-parallel context (parallel.LPContext) or None
@@ -111,6 +113,150 @@ class LookaheadDecoder:
         self.st.sel[:len(rows)].copy_(torch.tensor(rows, dtype=torch.int32), non_blocking=True)
         return len(rows)
 
+    # ---- stepwise API (bench.py drives single steps; greedy() is start + step until done) ----------
+    @torch.no_grad()
+    def start(self, prompt: Sequence[int], eos_token_id: Optional[int] = None, rng: Optional[random.Random] = None) -> None:
+        e, st = self.e, self.st
+        W, N, G, gs = self.W, self.N, self.G, self.gs
+        rng = rng if rng is not None else random
+        self.prompt = [int(t) for t in prompt]
+        # window init: W+N-3 random prompt tokens (lade/decoding.py:887-902, `copy_from`)
+        self.window0 = [rng.choice(self.prompt) for _ in range(W + N - 3)]
+        e.reset()
+        st.reset(self.window0, len(self.prompt), self.prompt)
+        if self.pool_from_prompt:                                   # :915-916
+            pt = torch.tensor(self.prompt, dtype=torch.int32, device=e.device)
+            call("lade_pool_fill_prompt", ptr(st.pool_tok), ptr(st.pool_cnt), st.V, G, gs, ptr(pt), len(self.prompt))
+        self.eos = -1 if eos_token_id is None else int(eos_token_id)
+        self.tokens = list(self.prompt)
+        self.steps, self.P, self.g, self.fill_level = 0, 0, 0, 0
+        self.finished_by_eos = False
+
+    # ---- steady step as ONE hipGraph ------------------------------------------------------------------
+    # Fixed shape: every steady step feeds T_max = (N-1)(W+G) tokens - the G-g unused candidate slots are
+    # padded with token 0 (they only see themselves and the input token, and verify ignores them) - and the
+    # cache length P is read by the kernels from the control block (dyn_P), so one captured graph serves
+    # every step: a step is one graph launch plus the read-back of the 24-word record.
+    def _steady_T(self) -> int:
+        return (self.N - 1) * (self.W + self.G)
+
+    def _graph_body(self) -> None:
+        e, st = self.e, self.st
+        W, N, G, gs = self.W, self.N, self.G, self.gs
+        T = self._steady_T()
+        cand_rows = G * gs
+        mask = StepMask.from_levels(1, self._level_sizes(N - 2), cand_rows, gs, 0)
+        call("lade_build_inputs", None, None, 1, ptr(st.window), st.wcap, ptr(st.ctl), N - 2, 0, -1, ptr(st.guess), -1, gs, cand_rows,
+             ptr(st.ids), ptr(st.pos), None)
+        logits = e.forward(st.ids, st.pos, mask, st.sel, 1 + W + cand_rows, dyn_P=st.ctl, n_splits=self._graph_splits)
+        ops.argmax_rows(logits, out=st.am)
+        call("lade_greedy_post_step", ptr(st.ctl), ptr(st.window), st.wcap, ptr(st.pool_tok), ptr(st.pool_cnt), st.V, W, N, G,
+             ptr(st.am), W, ptr(st.guess), T, cand_rows, 2, int(self.pool_from_prompt), ptr(st.tail), self.eos, ptr(st.record))
+        ops.kv_commit(e.kv, 0, 0, 0, ctl=st.ctl)
+        st.record_host.copy_(st.record, non_blocking=True)
+
+    def _capture_graph(self) -> None:
+        e, st = self.e, self.st
+        T = self._steady_T()
+        cand_rows = self.G * self.gs
+        rows = [0] + list(range(T - cand_rows - self.W, T - cand_rows)) + list(range(T - cand_rows, T))
+        st.sel[:len(rows)].copy_(torch.tensor(rows, dtype=torch.int32))
+        self._graph_splits = e.n_splits_for(T, min(e.S_max, 2048))
+        # warm-up on a side stream (library handles, allocator), with the state saved and restored
+        saved = [t.clone() for t in (st.ctl, st.window, st.pool_cnt, st.pool_tok, st.guess, st.tail)]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._graph_body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for t, sv in zip((st.ctl, st.window, st.pool_cnt, st.pool_tok, st.guess, st.tail), saved):
+            t.copy_(sv)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._graph_body()
+        # capture does not execute, but the warm-up wrote K/V rows past P: harmless (rows >= P are never read
+        # before being rewritten) 
+        self._graph = g
+        self._graph_eos = self.eos
+
+    def _step_graph(self) -> dict:
+        e, st = self.e, self.st
+        if self._graph is None or self._graph_eos != self.eos:
+            self._capture_graph()
+        T = self._steady_T()
+        if self.P + T > e.S_max:
+            raise cabi.LadeHipError(f"KV cache exhausted: P={self.P} + T={T} > S_max={e.S_max}")
+        P_before = self.P
+        self._graph.replay()
+        torch.cuda.current_stream().synchronize()
+        rec = st.record_host.tolist()
+        self.steps += 1
+        max_hit, n_accept, eos_hit, self.g, self.P = rec[0], rec[1], rec[2], rec[3], rec[4]
+        accepted = rec[8:8 + n_accept]
+        self.tokens += accepted
+        self.finished_by_eos = bool(eos_hit)
+        return dict(T=T, P_before=P_before, n_input=1, max_hit=max_hit, max_hit_idx=rec[5], accepted=list(accepted),
+                    first_guess=rec[6], g_next=self.g, P_after=self.P, phase=2)
+
+    @torch.no_grad()
+    def step(self, keep_trace: bool = False) -> dict:
+        """One decode step = one model forward over T tokens + the device-side post-step; returns the
+        host-visible record (accepted tokens, max_hit ...)."""
+        e, st = self.e, self.st
+        W, N, G, gs = self.W, self.N, self.G, self.gs
+        prompt, P, g, fill_level = self.prompt, self.P, self.g, self.fill_level
+        if self.use_graph and self.steps > 0 and fill_level >= N - 2:
+            return self._step_graph()
+        if self.steps == 0:                                          # prefill: prompt + L0, plain causal
+            phase, n_input = 0, len(prompt)
+            ids_h = prompt + self.window0
+            total = len(ids_h)
+            # long prompts run as causal chunks of <= max_T tokens over the growing cache; only the last
+            # chunk (which holds the last prompt token and the whole window) needs logits
+            last_len = min(total, max(e.max_T, len(self.window0) + 1))
+            done = 0
+            while total - done > last_len:
+                n = min(e.max_T, total - last_len - done)
+                st.ids[:n].copy_(torch.tensor(ids_h[done:done + n], dtype=torch.int32))
+                st.pos[:n].copy_(torch.arange(done, done + n, dtype=torch.int32))
+                e.forward(st.ids, st.pos, StepMask(T=n, P=done, is_prefill=True), st.sel, 0)
+                done += n
+            T = total - done
+            st.ids[:T].copy_(torch.tensor(ids_h[done:], dtype=torch.int32))
+            st.pos[:T].copy_(torch.arange(done, total, dtype=torch.int32))
+            mask = StepMask(T=T, P=done, is_prefill=True)
+            n_inp, cand_rows = len(self.window0), 0
+            n_input = len(prompt) - done                             # out row = last prompt token of this chunk
+        else:
+            phase = 2 if fill_level >= N - 2 else 1
+            n_input = 1
+            ls = self._level_sizes(fill_level)
+            cand_rows = g * gs if phase == 2 else 0
+            mask = StepMask.from_levels(n_input, ls, cand_rows, gs, P)
+            T = mask.T
+            call("lade_build_inputs", None, None, n_input, ptr(st.window), st.wcap, ptr(st.ctl), min(fill_level, N - 2), 0, -1,
+                 ptr(st.guess), g if phase == 2 else 0, gs, cand_rows, ptr(st.ids), ptr(st.pos), None)
+            n_inp = ls[-1]
+        # rows whose logits are needed: out row, last level's rows, candidate rows (:1578-1606)
+        rows = [n_input - 1] + list(range(T - cand_rows - n_inp, T - cand_rows)) + list(range(T - cand_rows, T))
+        n_sel = self._set_sel(rows)
+        logits = e.forward(st.ids, st.pos, mask, st.sel, n_sel)
+        ops.argmax_rows(logits, out=st.am)
+        call("lade_greedy_post_step", ptr(st.ctl), ptr(st.window), st.wcap, ptr(st.pool_tok), ptr(st.pool_cnt), st.V, W, N, G,
+             ptr(st.am), n_inp, ptr(st.guess), T, cand_rows, phase, int(self.pool_from_prompt), ptr(st.tail), self.eos, ptr(st.record))
+        ops.kv_commit(e.kv, 0, 0, 0, ctl=st.ctl)
+        rec = st.read_record()
+        self.steps += 1
+        max_hit, n_accept, eos_hit, self.g, self.P = rec[0], rec[1], rec[2], rec[3], rec[4]
+        accepted = rec[8:8 + n_accept]
+        self.tokens += accepted
+        if phase != 2:
+            self.fill_level += 1
+        self.finished_by_eos = bool(eos_hit)
+        return dict(T=T, P_before=mask.P, n_input=n_input, max_hit=max_hit, max_hit_idx=rec[5], accepted=list(accepted),
+                    first_guess=rec[6], g_next=self.g, P_after=self.P, phase=phase)
+
     @torch.no_grad()
     def greedy(self, prompt: Sequence[int], max_length: int, eos_token_id: Optional[int] = None,
                rng: Optional[random.Random] = None, keep_trace: bool = False) -> GenOut:
@@ -118,64 +264,16 @@ class LookaheadDecoder:
         if self.lp is not None and self.lp.R > 1:
             from .parallel import greedy_lp
             return greedy_lp(self, prompt, max_length, eos_token_id, rng, keep_trace)
-        e, st = self.e, self.st
-        W, N, G, gs = self.W, self.N, self.G, self.gs
-        rng = rng if rng is not None else random
-        prompt = [int(t) for t in prompt]
-        dev = e.device
-        # window init: W+N-3 random prompt tokens (lade/decoding.py:887-902, `copy_from`)
-        window0 = [rng.choice(prompt) for _ in range(W + N - 3)]
-        e.reset()
-        st.reset(window0, len(prompt), prompt)
-        if self.pool_from_prompt:                                   # :915-916
-            pt = torch.tensor(prompt, dtype=torch.int32, device=dev)
-            call("lade_pool_fill_prompt", ptr(st.pool_tok), ptr(st.pool_cnt), st.V, G, gs, ptr(pt), len(prompt))
-        eos = -1 if eos_token_id is None else int(eos_token_id)
-        tokens = list(prompt)
-        steps, P, g, fill_level = 0, 0, 0, 0
+        self.start(prompt, eos_token_id, rng)
         trace: List[dict] = []
-        finished = False
-        while not finished:
-            if steps == 0:                                          # prefill: prompt + L0, plain causal
-                phase, n_input = 0, len(prompt)
-                ids_h = prompt + window0
-                T = len(ids_h)
-                st.ids[:T].copy_(torch.tensor(ids_h, dtype=torch.int32))
-                st.pos[:T].copy_(torch.arange(T, dtype=torch.int32))
-                mask = StepMask(T=T, P=0, is_prefill=True)
-                n_inp, cand_rows = len(window0), 0
-            else:
-                phase = 2 if fill_level >= N - 2 else 1
-                n_input = 1
-                ls = self._level_sizes(fill_level)
-                cand_rows = g * gs if phase == 2 else 0
-                mask = StepMask.from_levels(n_input, ls, cand_rows, gs, P)
-                T = mask.T
-                call("lade_build_inputs", None, None, n_input, ptr(st.window), st.wcap, ptr(st.ctl), min(fill_level, N - 2), 0, -1,
-                     ptr(st.guess), g if phase == 2 else 0, gs, cand_rows, ptr(st.ids), ptr(st.pos), None)
-                n_inp = ls[-1]
-            # rows whose logits are needed: out row, last level's rows, candidate rows (:1578-1606)
-            rows = [n_input - 1] + list(range(T - cand_rows - n_inp, T - cand_rows)) + list(range(T - cand_rows, T))
-            n_sel = self._set_sel(rows)
-            logits = e.forward(st.ids, st.pos, mask, st.sel, n_sel)
-            ops.argmax_rows(logits, out=st.am)
-            call("lade_greedy_post_step", ptr(st.ctl), ptr(st.window), st.wcap, ptr(st.pool_tok), ptr(st.pool_cnt), st.V, W, N, G,
-                 ptr(st.am), n_inp, ptr(st.guess), T, cand_rows, phase, int(self.pool_from_prompt), ptr(st.tail), eos, ptr(st.record))
-            ops.kv_commit(e.kv, 0, 0, 0, ctl=st.ctl)
-            rec = st.read_record()
-            steps += 1
-            max_hit, n_accept, eos_hit, g, P = rec[0], rec[1], rec[2], rec[3], rec[4]
-            accepted = rec[8:8 + n_accept]
-            tokens += accepted
-            if phase != 2:
-                fill_level += 1
+        while True:
+            info = self.step()
             if keep_trace:
-                trace.append(dict(T=T, P_before=mask.P, n_input=n_input, max_hit=max_hit, max_hit_idx=rec[5], accepted=list(accepted),
-                                  first_guess=rec[6], g_next=g, P_after=P))
-            if eos_hit or len(tokens) >= max_length:
-                finished = True
-        generated = min(len(tokens), max_length) - len(prompt)
-        out = GenOut(tokens=tokens[:max_length], steps=steps, generated=generated, trace=trace)
+                trace.append(info)
+            if self.finished_by_eos or len(self.tokens) >= max_length:      # stopping criteria (:1204-1219)
+                break
+        generated = min(len(self.tokens), max_length) - len(self.prompt)
+        out = GenOut(tokens=self.tokens[:max_length], steps=self.steps, generated=generated, trace=trace)
         if CONFIG_MAP.get("DEBUG", 0):
-            CONFIG_MAP.setdefault("log", []).append([generated, steps, round(generated / steps, 2)])
+            CONFIG_MAP.setdefault("log", []).append([generated, self.steps, round(generated / self.steps, 2)])
         return out

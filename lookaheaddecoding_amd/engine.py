@@ -86,7 +86,7 @@ class StepEngine:
         self.ws_a = torch.empty(max_T, self.inter, dtype=dt, device=dev)
         self.max_splits = 32
         if dt != torch.float32:
-            self.part_o = torch.empty(self.max_splits * self.H * max_T * self.d, dtype=torch.float32, device=dev)
+            self.part_o = torch.empty(self.max_splits * self.H * max_T * self.d, dtype=dt, device=dev)
             self.part_ml = torch.empty(self.max_splits * self.H * max_T * 2, dtype=torch.float32, device=dev)
         else:
             self.part_o = self.part_ml = None
@@ -113,7 +113,7 @@ class StepEngine:
         """ids/pos: device int32 [>=T]; mask describes the step; sel_rows: device int32 [n_sel] rows whose
         logits are needed.  Appends the T new K/V rows at P..P+T and returns logits [n_sel, V] (model dtype,
         as `self.lm_head(hidden_states)` does at lade/models/modeling_llama.py:1541)."""
-        T, P = mask.T, mask.P
+        T, P = mask.T, mask.P                     # with dyn_P the kernels read P from the device (mask.P is then 0)
         if T > self.max_T or P + T > self.S_max:
             raise cabi.LadeHipError(f"step of T={T} tokens at P={P} exceeds the engine limits (max_T={self.max_T}, S_max={self.S_max})")
         H, Hkv, d = self.H, self.Hkv, self.d
@@ -136,6 +136,8 @@ class StepEngine:
             torch.matmul(h, lw["wgu"].t(), out=gu)
             ops.silu_mul(gu, out=a)
             torch.matmul(a, lw["wd"].t(), out=r)
+        if n_sel == 0:                                             # cache-filling chunk of a long prefill
+            return None
         xs = ops.gather_rows(x, sel_rows, rows=n_sel)
         rs = ops.gather_rows(r, sel_rows, rows=n_sel)
         hn = ops.add_rmsnorm(xs, rs, self.norm_w, self.eps)

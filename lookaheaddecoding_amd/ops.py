@@ -45,12 +45,14 @@ def _dev(t: torch.Tensor, name: str):
 
 
 def choose_splits(H: int, n_rep: int, T: int, S_tot: int, n_cu: int = 256) -> int:
-    """KV splits so that (row blocks x KV heads x splits) fills the 256 CUs without making a split
-    shorter than one 64-key tile."""
+    """KV splits of the lookahead attention.  The kernel is bound by per-CU ingest (~25 GB/s per CU), so the
+    grid (row blocks x KV heads x splits) should cover every CU once; a split is a whole number of 64-key
+    tiles and no split may be empty."""
     blocks = (H // n_rep) * ((n_rep * T + 127) // 128)
     tiles = max(1, (S_tot + 63) // 64)
-    want = max(1, (n_cu + blocks - 1) // blocks)
-    return max(1, min(want, tiles, 32))
+    want = max(1, min(n_cu // max(blocks, 1), tiles, 32))
+    tps = (tiles + want - 1) // want              # tiles per split
+    return (tiles + tps - 1) // tps               # drop the splits that would be empty
 
 
 def attn_fwd(q: torch.Tensor, k_cache: torch.Tensor, vt_cache: torch.Tensor, mask: StepMask, *, H: int, Hkv: int, d: int,
@@ -73,7 +75,7 @@ def attn_fwd(q: torch.Tensor, k_cache: torch.Tensor, vt_cache: torch.Tensor, mas
         n_splits = 1
     if n_splits > 1:
         if part_o is None:
-            part_o = torch.empty(n_splits, H, T, d, dtype=torch.float32, device=q.device)
+            part_o = torch.empty(n_splits, T, H, d, dtype=q.dtype, device=q.device)
         if part_ml is None:
             part_ml = torch.empty(n_splits, H, T, 2, dtype=torch.float32, device=q.device)
     a = AttnArgs(ptr(q), ptr(k_cache), ptr(vt_cache), ptr(out), ptr(part_o), ptr(part_ml), ptr(dyn_P),
@@ -85,17 +87,21 @@ def attn_fwd(q: torch.Tensor, k_cache: torch.Tensor, vt_cache: torch.Tensor, mas
     return out
 
 
-def time_attn(q, k_cache, vt_cache, mask: StepMask, *, H, Hkv, d, n_splits: int, reps: int = 20) -> float:
+def time_attn(q, k_cache, vt_cache, mask: StepMask, *, H, Hkv, d, n_splits: int, reps: int = 20, debug_timeline: bool = False):
     """Mean duration in microseconds of one attention launch (+combine), measured with hipEvents on the
     launch stream inside the library."""
     T, S_max = mask.T, k_cache.shape[1]
     out = torch.empty(T, H * d, dtype=q.dtype, device=q.device)
-    part_o = torch.empty(max(n_splits, 1), H, T, d, dtype=torch.float32, device=q.device)
-    part_ml = torch.empty(max(n_splits, 1), H, T, 2, dtype=torch.float32, device=q.device)
+    part_o = torch.empty(max(n_splits, 1), T, H, d, dtype=q.dtype, device=q.device)
+    n_ml = max(n_splits, 1) * H * T * 2
+    part_ml = torch.zeros(n_ml + 16 * 4096, dtype=torch.float32, device=q.device)   # + room for LADE_ATTN_DBG=16 timestamps
     a = AttnArgs(ptr(q), ptr(k_cache), ptr(vt_cache), ptr(out), ptr(part_o), ptr(part_ml), None, q.stride(0), out.stride(0),
                  H, Hkv, d, S_max, dtype_code(q), n_splits, 1.0 / math.sqrt(d), mask.c_struct())
     us = C.c_float(0.0)
     call("lade_time_attn", C.byref(a), reps, C.byref(us))
+    if debug_timeline:
+        torch.cuda.synchronize()
+        return float(us.value), part_ml[n_ml:].view(torch.int64).view(-1, 8).cpu()
     return float(us.value)
 
 

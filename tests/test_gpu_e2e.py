@@ -84,3 +84,28 @@ def _oracle_margin_check(cfg, w, dtype, tokens, n_prompt, tol):
         if row.max().item() - row[tokens[i + 1]].item() > tol:
             return False
     return True
+
+
+def test_graph_mode_identical_to_reference_traces_fp32():
+    """steady steps replayed as one captured hipGraph (fixed T_max, padded candidates, P read on device):
+    same tokens, same step count, same per-step acceptance as the reference."""
+    from lookaheaddecoding_amd.decoding import LookaheadDecoder
+    d = load("e2e_greedy.json")
+    for run in d["runs"]:
+        cfg, w, eng = make_engine(run, torch.float32)
+        dec = LookaheadDecoder(eng, run["W"], run["N"], run["G"], pool_from_prompt=bool(run["pool_from_prompt"]), use_graph=True)
+        out = dec.greedy(run["prompt"], run["max_length"], eos_token_id=run["eos"], rng=random.Random(run["seed"]), keep_trace=True)
+        assert out.tokens == run["tokens"], (run["model"], run["W"], run["N"], run["G"], run["seed"])
+        assert out.steps == run["steps"]
+        for i, (mine, ref) in enumerate(zip(out.trace, run["trace"])):
+            assert mine["P_before"] == ref["P"] and mine["first_guess"] == ref["out_argmax"], i
+
+
+def test_graph_mode_bf16_equals_eager_mode():
+    from lookaheaddecoding_amd.decoding import LookaheadDecoder
+    prompt = [1, 5, 9, 17, 33, 5, 9, 17, 44, 5, 9]
+    cfg, w, eng = make_engine("tiny-d128", torch.bfloat16, 2, 0.05)
+    a = LookaheadDecoder(eng, 15, 5, 15).greedy(prompt, len(prompt) + 60, rng=random.Random(1), keep_trace=True)
+    b = LookaheadDecoder(eng, 15, 5, 15, use_graph=True).greedy(prompt, len(prompt) + 60, rng=random.Random(1), keep_trace=True)
+    assert a.tokens == b.tokens and a.steps == b.steps
+    assert [t["max_hit"] for t in a.trace] == [t["max_hit"] for t in b.trace]

@@ -1,0 +1,56 @@
+"""Microbenchmark of the lookahead attention kernel (run on the GPU box):
+python tools/attn_bench.py [--T 60 120] [--P 1024 2048 4096] [--splits 1 4 6 8 9 12 18]"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from lookaheaddecoding_amd import ops
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--T", type=int, nargs="+", default=[60, 120])
+    ap.add_argument("--P", type=int, nargs="+", default=[1024, 4096])
+    ap.add_argument("--splits", type=int, nargs="+", default=[0])
+    ap.add_argument("--H", type=int, default=32)
+    ap.add_argument("--Hkv", type=int, default=32)
+    ap.add_argument("--d", type=int, default=128)
+    ap.add_argument("--reps", type=int, default=200)
+    a = ap.parse_args()
+    W, N = 15, 5
+    gs = N - 1
+    for T in a.T:
+        g = max(0, (T - (N - 1) * W) // gs)
+        T = (N - 1) * W + g * gs
+        for P in a.P:
+            S_max = (P + T + 63) // 64 * 64 + 64
+            q = torch.randn(T, (a.H + 2 * a.Hkv) * a.d, device="cuda").bfloat16()
+            k = torch.randn(a.Hkv, S_max, a.d, device="cuda").bfloat16()
+            vt = torch.randn(a.Hkv, a.d, S_max, device="cuda").bfloat16()
+            mask = ops.StepMask.from_levels(1, [W - 1] + [W] * (N - 2), g * gs, gs, P)
+            alg = 2 * (2 * a.Hkv * (P + T) * a.d + 2 * a.H * T * a.d)
+            for ns in a.splits:
+                n = ns if ns > 0 else ops.choose_splits(a.H, a.H // a.Hkv, T, P + T)
+                if os.environ.get("LADE_ATTN_DBG") == "16":
+                    us, tl = ops.time_attn(q, k, vt, mask, H=a.H, Hkv=a.Hkv, d=a.d, n_splits=n, reps=a.reps, debug_timeline=True)
+                    nwg = a.Hkv * n * ((T * (a.H // a.Hkv) + 127) // 128)
+                    tl = tl[:nwg].double()
+                    rel = tl[:, 1:7] - tl[:, :1]
+                    order = torch.argsort(tl[:, 0])
+                    half = len(order) // 2
+                    for nm, idx in (("first-started half", order[:half]), ("second half", order[half:])):
+                        rr = rel[idx]
+                        ok = (rr[:, 1] > 0)
+                        print("   ", nm, "mean stamps:", [int(x) for x in rr[ok].mean(0).tolist()], "start offset mean:", int((tl[idx, 0] - tl[:, 0].min()).mean()))
+                    print("   stamps (cycles since WG start) mean:", [int(x) for x in rel.mean(0).tolist()], "max:", [int(x) for x in rel.max(0)[0].tolist()],
+                          " WG start spread:", int(tl[:, 0].max() - tl[:, 0].min()), " kernel span:", int(tl[:, 6].max() - tl[:, 0].min()))
+                else:
+                    us = ops.time_attn(q, k, vt, mask, H=a.H, Hkv=a.Hkv, d=a.d, n_splits=n, reps=a.reps)
+                print(f"T={T:4d} P={P:5d} splits={n:3d}  {us:8.2f} us   {alg / us / 1e3:8.1f} GB/s  ({alg / us / 1e3 / 8000 * 100:5.1f}% of 8 TB/s)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
