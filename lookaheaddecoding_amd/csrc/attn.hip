@@ -590,11 +590,12 @@ static int validate(const lade_attn_args* a) {
     LADE_REQUIRE(a->n_splits == 1 || (a->part_o && a->part_ml), LADE_E_ARG, "lade_attn: split-KV needs partial buffers");
     if (!a->mask.is_prefill) {
         const lade_mask_params& m = a->mask;
-        LADE_REQUIRE(m.s > 0 && m.gs > 0 && m.lguess >= 0 && m.lguess % m.gs == 0 && m.level_offset >= 0 && m.dist_offset >= 0,
+        LADE_REQUIRE(m.s >= 0 && m.gs > 0 && m.lguess >= 0 && m.lguess % m.gs == 0 && m.level_offset >= 0 && m.dist_offset >= 0,
                      LADE_E_ARG, "lade_attn: bad mask params s=%d gs=%d lguess=%d lo=%d do=%d", m.s, m.gs, m.lguess,
                      m.level_offset, m.dist_offset);
+        // s == 0: a lookahead-parallel rank that owns no window column feeds only the L0 prefix (all causal rows)
         const int body = m.T - m.lguess - (m.level_offset + m.dist_offset);
-        LADE_REQUIRE(body >= 0 && body % m.s == 0, LADE_E_ARG,
+        LADE_REQUIRE(body >= 0 && (m.s > 0 ? body % m.s == 0 : body == 0), LADE_E_ARG,
                      "lade_attn: T=%d is not offsets(%d)+k*s(%d)+lguess(%d)", m.T, m.level_offset + m.dist_offset, m.s, m.lguess);
     }
     return LADE_OK;

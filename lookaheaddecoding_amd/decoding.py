@@ -133,62 +133,70 @@ class LookaheadDecoder:
         self.finished_by_eos = False
 
     # ---- steady step as ONE hipGraph ------------------------------------------------------------------
-    # Fixed shape: every steady step feeds T_max = (N-1)(W+G) tokens - the G-g unused candidate slots are
-    # padded with token 0 (they only see themselves and the input token, and verify ignores them) - and the
-    # cache length P is read by the kernels from the control block (dyn_P), so one captured graph serves
-    # every step: a step is one graph launch plus the read-back of the 24-word record.
-    def _steady_T(self) -> int:
-        return (self.N - 1) * (self.W + self.G)
+    # Fixed shapes: a graph is captured per candidate-count bucket gcap in {0, G/4, G/2, G}; a step with g
+    # candidates replays the smallest bucket >= g and feeds T = (N-1)(W+gcap) tokens - the gcap-g unused
+    # candidate slots are padded with token 0 (they only see themselves and the input token, and verify
+    # ignores them).  The cache length P is read by the kernels from the control block (dyn_P), so the same
+    # graphs serve every step: a step is one graph launch plus the read-back of the 24-word record.
+    def _buckets(self) -> List[int]:
+        G = self.G
+        return sorted({0, (G + 3) // 4, (G + 1) // 2, G})
 
-    def _graph_body(self) -> None:
+    def _graph_body(self, gcap: int) -> None:
         e, st = self.e, self.st
         W, N, G, gs = self.W, self.N, self.G, self.gs
-        T = self._steady_T()
-        cand_rows = G * gs
+        cand_rows = gcap * gs
         mask = StepMask.from_levels(1, self._level_sizes(N - 2), cand_rows, gs, 0)
+        T = mask.T
         call("lade_build_inputs", None, None, 1, ptr(st.window), st.wcap, ptr(st.ctl), N - 2, 0, -1, ptr(st.guess), -1, gs, cand_rows,
              ptr(st.ids), ptr(st.pos), None)
-        logits = e.forward(st.ids, st.pos, mask, st.sel, 1 + W + cand_rows, dyn_P=st.ctl, n_splits=self._graph_splits)
+        logits = e.forward(st.ids, st.pos, mask, self._graph_sel[gcap], 1 + W + cand_rows, dyn_P=st.ctl, n_splits=self._graph_splits[gcap])
         ops.argmax_rows(logits, out=st.am)
         call("lade_greedy_post_step", ptr(st.ctl), ptr(st.window), st.wcap, ptr(st.pool_tok), ptr(st.pool_cnt), st.V, W, N, G,
              ptr(st.am), W, ptr(st.guess), T, cand_rows, 2, int(self.pool_from_prompt), ptr(st.tail), self.eos, ptr(st.record))
         ops.kv_commit(e.kv, 0, 0, 0, ctl=st.ctl)
         st.record_host.copy_(st.record, non_blocking=True)
 
-    def _capture_graph(self) -> None:
+    def _capture_graphs(self) -> None:
         e, st = self.e, self.st
-        T = self._steady_T()
-        cand_rows = self.G * self.gs
-        rows = [0] + list(range(T - cand_rows - self.W, T - cand_rows)) + list(range(T - cand_rows, T))
-        st.sel[:len(rows)].copy_(torch.tensor(rows, dtype=torch.int32))
-        self._graph_splits = e.n_splits_for(T, min(e.S_max, 2048))
-        # warm-up on a side stream (library handles, allocator), with the state saved and restored
-        saved = [t.clone() for t in (st.ctl, st.window, st.pool_cnt, st.pool_tok, st.guess, st.tail)]
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            self._graph_body()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        for t, sv in zip((st.ctl, st.window, st.pool_cnt, st.pool_tok, st.guess, st.tail), saved):
-            t.copy_(sv)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._graph_body()
-        # capture does not execute, but the warm-up wrote K/V rows past P: harmless (rows >= P are never read
-        # before being rewritten) 
-        self._graph = g
+        W, N, gs = self.W, self.N, self.gs
+        self._graphs, self._graph_sel, self._graph_splits, self._graph_T = {}, {}, {}, {}
+        state = (st.ctl, st.window, st.pool_cnt, st.pool_tok, st.guess, st.tail)
+        saved = [t.clone() for t in state]
+        for gcap in self._buckets():
+            cand_rows = gcap * gs
+            T = (N - 1) * W + cand_rows
+            rows = [0] + list(range(T - cand_rows - W, T - cand_rows)) + list(range(T - cand_rows, T))
+            self._graph_sel[gcap] = torch.tensor(rows, dtype=torch.int32, device=e.device)
+            self._graph_splits[gcap] = e.n_splits_for(T, min(e.S_max, max(self.P + T, 1024)))
+            self._graph_T[gcap] = T
+            # warm-up on a side stream (library handles, allocator), then restore the integer state;
+            # the K/V rows it wrote lie at >= P and are rewritten by the real step before being read
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._graph_body(gcap)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            for t, sv in zip(state, saved):
+                t.copy_(sv)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._graph_body(gcap)
+            self._graphs[gcap] = g
+        self._graph = True
         self._graph_eos = self.eos
 
     def _step_graph(self) -> dict:
         e, st = self.e, self.st
         if self._graph is None or self._graph_eos != self.eos:
-            self._capture_graph()
-        T = self._steady_T()
+            self._capture_graphs()
+        gcap = min(b for b in self._graphs if b >= self.g)
+        T = self._graph_T[gcap]
         if self.P + T > e.S_max:
             raise cabi.LadeHipError(f"KV cache exhausted: P={self.P} + T={T} > S_max={e.S_max}")
         P_before = self.P
-        self._graph.replay()
+        self._graphs[gcap].replay()
         torch.cuda.current_stream().synchronize()
         rec = st.record_host.tolist()
         self.steps += 1

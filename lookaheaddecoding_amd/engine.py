@@ -49,6 +49,8 @@ class StepEngine:
         self.cfg = dict(cfg)
         self.dtype = dtype
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.hidden, self.inter = cfg["hidden"], cfg["inter"]
         self.L, self.H, self.Hkv, self.d, self.V = cfg["layers"], cfg["heads"], cfg["kv_heads"], cfg["head_dim"], cfg["vocab"]
         self.eps = float(cfg["eps"])
@@ -90,7 +92,10 @@ class StepEngine:
             self.part_ml = torch.empty(self.max_splits * self.H * max_T * 2, dtype=torch.float32, device=dev)
         else:
             self.part_o = self.part_ml = None
-        self.n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        try:
+            self.n_cu = torch.cuda.get_device_properties(self.device.index).multi_processor_count
+        except AssertionError:      # device count not initialised on this thread yet
+            self.n_cu = 256
 
     # ---- views --------------------------------------------------------------------------------
     def k_cache(self, layer: int) -> torch.Tensor:

@@ -1,0 +1,204 @@
+"""Lookahead parallelism (LP): the W window columns and the g candidates of a step are sharded over the
+R GPUs of a node; every rank holds a full model replica and the KV cache of the accepted prefix.
+
+Reference: lade/decoding.py:905-906 (window broadcast), :956-963 (candidate shard), :973-986 (window
+shard), :1023-1024, 1043-1046, 1055-1058, 1088-1107 (per-step object collectives), :1148-1153 (on a
+hit the cache is cut back and the accepted tokens are re-fed), lade/lade_distributed.py.
+
+Re-design for RCCL over xGMI: the reference issues four pickled *object* collectives per step (each
+a size exchange + payload round on the host).  Here every rank packs ONE fixed-size int32 record on
+the device (`lade_lp_pack`: first_guess, its best verification result, its new window columns), the
+host issues ONE `all_gather_into_tensor` (RCCL; tens of bytes, latency bound, so a single small
+collective on the compute stream), and every rank applies the same deterministic reduction on the
+device (`lade_lp_reduce_apply`).  Rank-local state (window, pool, control block) therefore stays
+bit-identical on all ranks without further traffic.
+
+The orchestration (`greedy_lp`) is written against a small backend interface so that the partition /
+exchange / loop logic can be exercised on CPU with gloo (world_size 2) in the test-suite, where a
+test-only backend stands in for the HIP kernels; the product backend is `HipLPBackend` (no CPU path).
+"""
+from __future__ import annotations
+
+import random
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+REC_HEAD = 4           # first_guess, max_hit, max_hit_idx, n_inp
+
+
+@dataclass
+class LPContext:
+    rank: int
+    world: int
+    group: Optional[object] = None
+
+    @property
+    def R(self) -> int:
+        return self.world
+
+
+def window_shard(window_len: int, R: int, r: int) -> Tuple[int, int]:
+    """Columns [c0, c1) of the window owned by rank r; window_len = len(L0) + 1 (lade/decoding.py:974-977)."""
+    split = (window_len + R - 1) // R
+    return min(split * r, window_len), min(split * (r + 1), window_len)
+
+
+def guess_shard(g: int, R: int, r: int) -> Tuple[int, int]:
+    """Candidates [lo, hi) verified by rank r (lade/decoding.py:958-961)."""
+    cnt = (g + R - 1) // R
+    return min(cnt * r, g), min(cnt * (r + 1), g)
+
+
+def shard_level_sizes(level_lens: Sequence[int], c0: int, c1: int) -> List[int]:
+    """Level sizes of rank r's step: the whole L0 prefix up to its last column, and its own columns of
+    every higher level (lade/decoding.py:981-984)."""
+    out = [min(c1 - 1, level_lens[0])]
+    for ln in level_lens[1:]:
+        out.append(max(min(c1, ln) - min(c0, ln), 0))
+    return out
+
+
+def rec_words(gs: int, wcap: int) -> int:
+    return REC_HEAD + gs + wcap
+
+
+class HipLPBackend:
+    """Rank-local device work of one LP step on the HIP kernels (wraps a LookaheadDecoder's engine + state)."""
+
+    def __init__(self, dec):
+        from . import ops
+        from .cabi import call, ptr
+        self.dec, self.ops, self.call, self.ptr = dec, ops, call, ptr
+        st = dec.st
+        self.rw = rec_words(dec.gs, st.wcap)
+        dev = dec.e.device
+        self.rec = torch.zeros(self.rw, dtype=torch.int32, device=dev)
+        self.scratch = torch.zeros(max(st.wcap, dec.W) * 2 + 64, dtype=torch.int32, device=dev)
+        self.device = dev
+
+    def begin(self, prompt: Sequence[int], window0: Sequence[int], eos: int) -> None:
+        d = self.dec
+        d.e.reset()
+        d.st.reset(window0, len(prompt), prompt)
+        self.prompt = list(prompt)
+        self.window0 = list(window0)
+
+    def local_step(self, phase: int, P: int, n_input: int, level_lens: Sequence[int], c0: int, c1: int, g: int, glo: int, ghi: int):
+        """Builds this rank's inputs, runs the forward, and packs its record (device tensor [rw])."""
+        from .ops import StepMask
+        d, st, e = self.dec, self.dec.st, self.dec.e
+        gs, N = d.gs, d.N
+        call, ptr = self.call, self.ptr
+        g_local = ghi - glo
+        cand_rows = g_local * gs if phase == 2 else 0
+        if phase == 0:
+            ids_h = self.prompt + self.window0[: c1 - 1]
+            total = len(ids_h)
+            n_win = c1 - 1
+            last_len = min(total, max(e.max_T, n_win + 1))
+            done = 0
+            while total - done > last_len:
+                n = min(e.max_T, total - last_len - done)
+                st.ids[:n].copy_(torch.tensor(ids_h[done:done + n], dtype=torch.int32))
+                st.pos[:n].copy_(torch.arange(done, done + n, dtype=torch.int32))
+                e.forward(st.ids, st.pos, StepMask(T=n, P=done, is_prefill=True), st.sel, 0)
+                done += n
+            T = total - done
+            st.ids[:T].copy_(torch.tensor(ids_h[done:], dtype=torch.int32))
+            st.pos[:T].copy_(torch.arange(done, total, dtype=torch.int32))
+            mask = StepMask(T=T, P=done, is_prefill=True)
+            n_inp = n_win
+            out_row = len(self.prompt) - done - 1
+        else:
+            ls = shard_level_sizes(level_lens, c0, c1)
+            mask = StepMask.from_levels(n_input, ls, cand_rows, gs, P)
+            T = mask.T
+            guess_ptr = st.guess.data_ptr() + 4 * glo * gs
+            call("lade_build_inputs", None, None, n_input, ptr(st.window), st.wcap, ptr(st.ctl), len(level_lens) - 1, c0, c1,
+                 guess_ptr, g_local if phase == 2 else 0, gs, cand_rows, ptr(st.ids), ptr(st.pos), None)
+            n_inp = ls[-1]
+            out_row = n_input - 1
+        rows = [out_row] + list(range(T - cand_rows - n_inp, T - cand_rows)) + list(range(T - cand_rows, T))
+        st.sel[:len(rows)].copy_(torch.tensor(rows, dtype=torch.int32))
+        logits = e.forward(st.ids, st.pos, mask, st.sel, len(rows))
+        self.ops.argmax_rows(logits, out=st.am)
+        am = st.am.data_ptr()
+        guess_ptr = st.guess.data_ptr() + 4 * glo * gs
+        call("lade_lp_pack", am, am + 4, n_inp, guess_ptr, am + 4 * (1 + n_inp), g_local if phase == 2 else 0, gs, st.wcap, ptr(self.rec), self.rw)
+        return self.rec
+
+    def apply(self, all_rec: torch.Tensor, R: int, phase: int) -> List[int]:
+        d, st = self.dec, self.dec.st
+        call, ptr = self.call, self.ptr
+        call("lade_lp_reduce_apply", ptr(all_rec), R, self.rw, st.wcap, ptr(st.ctl), ptr(st.window), st.wcap, ptr(st.pool_tok), ptr(st.pool_cnt),
+             st.V, d.W, d.N, d.G, phase, ptr(st.guess), ptr(self.scratch), ptr(st.record))
+        return st.read_record()
+
+    def new_gather_buffer(self, R: int) -> torch.Tensor:
+        return torch.zeros(R * self.rw, dtype=torch.int32, device=self.device)
+
+    def broadcast_window(self, window0: List[int], lp: LPContext) -> List[int]:
+        t = torch.tensor(window0, dtype=torch.int32, device=self.device)
+        dist.broadcast(t, src=0, group=lp.group)
+        return t.tolist()
+
+
+def greedy_lp(dec, prompt: Sequence[int], max_length: int, eos_token_id: Optional[int] = None,
+              rng: Optional[random.Random] = None, keep_trace: bool = False, backend=None):
+    """Greedy lookahead decoding under lookahead parallelism (jacobi_greedy_search_multilevel with
+    DIST_WORKERS > 1, lade/decoding.py:697-1259).  `dec` supplies W, N, G and the LPContext; `backend`
+    defaults to the HIP backend."""
+    from .decoding import GenOut
+    lp: LPContext = dec.lp
+    R, r = lp.R, lp.rank
+    W, N, G = dec.W, dec.N, dec.G
+    gs = N - 1
+    if R > W:
+        raise ValueError(f"lookahead parallelism needs DIST_WORKERS ({R}) <= WINDOW_SIZE ({W})")
+    be = backend if backend is not None else HipLPBackend(dec)
+    rng = rng if rng is not None else random
+    prompt = [int(t) for t in prompt]
+    # every rank draws its own window, rank 0's is broadcast (lade/decoding.py:902-906)
+    window0 = [rng.choice(prompt) for _ in range(W + N - 3)]
+    window0 = be.broadcast_window(window0, lp)
+    eos = -1 if eos_token_id is None else int(eos_token_id)
+    be.begin(prompt, window0, eos)
+    all_rec = be.new_gather_buffer(R)
+    tokens = list(prompt)
+    steps, P, g, fill_level, n_input = 0, 0, 0, 0, len(prompt)
+    trace: List[dict] = []
+    while True:
+        phase = 0 if steps == 0 else (2 if fill_level >= N - 2 else 1)
+        # level lengths before this step (see LookaheadDecoder._level_sizes)
+        if fill_level == 0:
+            level_lens = [W + N - 3]
+        elif fill_level >= N - 2:
+            level_lens = [W - 1] + [W] * (N - 2)
+        else:
+            level_lens = [W + N - 3 - fill_level] + [W + N - 2 - fill_level] * fill_level
+        c0, c1 = window_shard(level_lens[0] + 1, R, r)
+        glo, ghi = guess_shard(g, R, r) if phase == 2 else (0, 0)
+        rec = be.local_step(phase, P, n_input, level_lens, c0, c1, g, glo, ghi)
+        dist.all_gather_into_tensor(all_rec, rec, group=lp.group)           # the ONE exchange of the step
+        out = be.apply(all_rec, R, phase)
+        steps += 1
+        max_hit, n_accept, g, P = out[0], out[1], out[3], out[4]
+        accepted = out[8:8 + n_accept]
+        # EOS scan (lade/decoding.py:1167-1177): the reference keeps everything up to and including EOS
+        finished = False
+        if eos >= 0 and eos in accepted:
+            accepted = accepted[:accepted.index(eos) + 1]
+            finished = True
+        tokens += accepted
+        n_input = 1 + max_hit                                               # re-feed the hits (:1148-1153)
+        if phase != 2:
+            fill_level += 1
+        if keep_trace:
+            trace.append(dict(phase=phase, max_hit=max_hit, accepted=list(accepted), c0=c0, c1=c1, glo=glo, ghi=ghi, P_after=P, g_next=g))
+        if finished or len(tokens) >= max_length:
+            break
+    generated = min(len(tokens), max_length) - len(prompt)
+    return GenOut(tokens=tokens[:max_length], steps=steps, generated=generated, trace=trace)

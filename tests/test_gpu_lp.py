@@ -1,0 +1,145 @@
+"""Lookahead parallelism on the HIP kernels.  Only one GPU is available per test box, so the R ranks
+run as R threads of one process on cuda:0 (each with its own engine, window, pool and KV cache) and the
+collectives are swapped for an in-process exchange; the rank-local kernels (sharded input assembly,
+lade_lp_pack, lade_lp_reduce_apply) and the orchestration are the product's.  Checked against the
+reference's own gloo runs: tokens, step count and every rank's step inputs.  A real 1-rank RCCL group
+is exercised as well."""
+import json
+import os
+import random
+import threading
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+from conftest import GOLDEN
+from lookaheaddecoding_amd.weights import make_config, random_weights_numpy
+
+
+class ThreadExchange:
+    def __init__(self, R):
+        self.R = R
+        self.bar = threading.Barrier(R)
+        self.slots = [None] * R
+        self.lock = threading.Lock()
+
+    def all_gather(self, rank, out, inp):
+        torch.cuda.current_stream().synchronize()
+        self.slots[rank] = inp.clone()
+        self.bar.wait()
+        out.copy_(torch.cat([s.to(out.device) for s in self.slots]))
+        torch.cuda.current_stream().synchronize()
+        self.bar.wait()
+
+    def broadcast(self, rank, t):
+        if rank == 0:
+            self.slots[0] = t.clone()
+        self.bar.wait()
+        t.copy_(self.slots[0])
+        self.bar.wait()
+
+
+def _run_rank(rank, R, run, ex, results, errors):
+    try:
+        from lookaheaddecoding_amd import parallel
+        from lookaheaddecoding_amd.decoding import LookaheadDecoder
+        from lookaheaddecoding_amd.engine import StepEngine
+        torch.cuda.set_device(0)
+        cfg = make_config(run["model"], max_pos=512)
+        w = {k: torch.as_tensor(v) for k, v in random_weights_numpy(cfg, seed=run["model_seed"], std=run["std"]).items()}
+        eng = StepEngine(cfg, w, dtype=torch.float32, max_seq=512, max_T=320)
+        dec = LookaheadDecoder(eng, run["W"], run["N"], run["G"], lp=parallel.LPContext(rank=rank, world=R))
+        be = parallel.HipLPBackend(dec)
+        be.broadcast_window = lambda w0, lp: (lambda t: (ex.broadcast(rank, t), t.tolist())[1])(torch.tensor(w0, dtype=torch.int32, device="cuda"))
+        ids_per_step = []
+        orig = be.local_step
+
+        def rec_step(phase, P, n_input, level_lens, c0, c1, g, glo, ghi):
+            r = orig(phase, P, n_input, level_lens, c0, c1, g, glo, ghi)
+            ls = parallel.shard_level_sizes(level_lens, c0, c1)
+            T = (len(run["prompt"]) + c1 - 1) if phase == 0 else n_input + sum(ls) + (ghi - glo) * (run["N"] - 1)
+            ids_per_step.append(dec.st.ids[:T].cpu().tolist() if phase != 0 else None)
+            return r
+
+        be.local_step = rec_step
+        with torch.cuda.stream(torch.cuda.Stream()):
+            out = _greedy_lp_patched(parallel, dec, run, be, ex, rank)
+        results[rank] = (out.tokens, out.steps, ids_per_step)
+    except Exception as e:  # pragma: no cover
+        import traceback
+        errors.append((rank, traceback.format_exc()))
+        try:
+            ex.bar.abort()
+        except Exception:
+            pass
+
+
+def _greedy_lp_patched(parallel, dec, run, be, ex, rank):
+    # thread-local replacement of the collective used inside greedy_lp
+    real = parallel.dist.all_gather_into_tensor
+    tl = threading.local()
+
+    def ag(out, inp, group=None):
+        ex.all_gather(rank, out, inp)
+
+    class D:
+        all_gather_into_tensor = staticmethod(ag)
+        broadcast = staticmethod(lambda *a, **k: None)
+
+    # greedy_lp looks `dist` up in its module globals: give this thread its own view via a wrapper module object
+    import types
+    mod = types.ModuleType("parallel_thread")
+    mod.__dict__.update(parallel.__dict__)
+    mod.dist = D
+    code = parallel.greedy_lp.__code__
+    fn = types.FunctionType(code, mod.__dict__, "greedy_lp", parallel.greedy_lp.__defaults__)
+    fn.__kwdefaults__ = parallel.greedy_lp.__kwdefaults__
+    return fn(dec, run["prompt"], run["max_length"], rng=random.Random(run["seed"] + 1000 * rank), backend=be, keep_trace=True)
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2, 3])
+def test_lp_hip_kernels_match_reference_gloo_runs(idx):
+    with open(os.path.join(GOLDEN, "e2e_lp.json")) as f:
+        run = json.load(f)["runs"][idx]
+    R = run["R"]
+    torch.cuda.init()
+    torch.zeros(1, device="cuda")
+    ex = ThreadExchange(R)
+    results, errors = {}, []
+    threads = [threading.Thread(target=_run_rank, args=(r, R, run, ex, results, errors)) for r in range(R)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors[0][1]
+    for rank in range(R):
+        toks, steps, ids = results[rank]
+        assert toks == run["tokens"], (rank, R)
+        assert steps == run["steps"]
+        for i, (mine, ref) in enumerate(zip(ids, run["rank_traces"][rank])):
+            if mine is not None:
+                assert mine == ref["ids"], (rank, i)
+
+
+def test_lp_single_rank_over_rccl():
+    """world_size 1 through the real RCCL backend: tokens and step count of the reference."""
+    from lookaheaddecoding_amd import parallel
+    from lookaheaddecoding_amd.decoding import LookaheadDecoder
+    from lookaheaddecoding_amd.engine import StepEngine
+    with open(os.path.join(GOLDEN, "e2e_greedy.json")) as f:
+        run = json.load(f)["runs"][0]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29655")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        cfg = make_config(run["model"], max_pos=512)
+        w = {k: torch.as_tensor(v) for k, v in random_weights_numpy(cfg, seed=run["model_seed"], std=run["std"]).items()}
+        eng = StepEngine(cfg, w, dtype=torch.float32, max_seq=512, max_T=320)
+        dec = LookaheadDecoder(eng, run["W"], run["N"], run["G"], lp=parallel.LPContext(rank=0, world=1))
+        out = parallel.greedy_lp(dec, run["prompt"], run["max_length"], rng=random.Random(run["seed"]))
+        assert out.tokens == run["tokens"] and out.steps == run["steps"]
+    finally:
+        dist.destroy_process_group()

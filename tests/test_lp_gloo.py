@@ -1,0 +1,102 @@
+"""Lookahead parallelism on CPU: the product's LP orchestration (sharding, one all-gather per step,
+loop control) over gloo with world_size 2 and 3, against the reference's own gloo runs (golden)."""
+import json
+import os
+import random
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import GOLDEN, ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, R, port, run, q):
+    import sys
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import lade_oracle as O
+    from lp_oracle_backend import OracleLPBackend
+    from lookaheaddecoding_amd.parallel import LPContext, greedy_lp
+    from lookaheaddecoding_amd.weights import make_config, random_weights_numpy
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=R)
+    cfg = make_config(run["model"], max_pos=512)
+    w = random_weights_numpy(cfg, seed=run["model_seed"], std=run["std"])
+    model = O.OracleLlama(cfg, {k: torch.as_tensor(v) for k, v in w.items()})
+
+    class Dec:      # what greedy_lp needs from a decoder: the configuration and the LP context
+        pass
+
+    d = Dec()
+    d.W, d.N, d.G, d.gs = run["W"], run["N"], run["G"], run["N"] - 1
+    d.lp = LPContext(rank=rank, world=R)
+    be = OracleLPBackend(model, d.W, d.N, d.G)
+    ids_per_step = []
+    orig = be.local_step
+
+    def rec_step(*a, **k):
+        r = orig(*a, **k)
+        ids_per_step.append(list(be.last_ids))
+        return r
+
+    be.local_step = rec_step
+    out = greedy_lp(d, run["prompt"], run["max_length"], rng=random.Random(run["seed"] + 1000 * rank), backend=be, keep_trace=True)
+    q.put((rank, out.tokens, out.steps, ids_per_step))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2, 3])
+def test_lp_orchestration_matches_reference_gloo_runs(idx):
+    with open(os.path.join(GOLDEN, "e2e_lp.json")) as f:
+        runs = json.load(f)["runs"]
+    run = runs[idx]
+    R = run["R"]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, R, port, run, q)) for r in range(R)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(R))
+    for p in procs:
+        p.join(timeout=60)
+    for rank, toks, steps, ids in res:
+        assert toks == run["tokens"], (rank, R)
+        assert steps == run["steps"]
+        ref_ids = [t["ids"] for t in run["rank_traces"][rank]]
+        assert ids == ref_ids, f"rank {rank}: step inputs differ from the reference's rank trace"
+
+
+def test_shard_math_matches_reference_formulas():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import lade_oracle as O
+    from lookaheaddecoding_amd.parallel import guess_shard, shard_level_sizes, window_shard
+    for W in (1, 5, 7, 15, 20):
+        for N in (3, 5, 7):
+            past = [list(range(W - 1))] + [list(range(W)) for _ in range(N - 2)]
+            for R in (1, 2, 3, 4, 8):
+                for r in range(R):
+                    pt, ws, we = O.lp_window_shard(past, R, r)
+                    assert (ws, we) == window_shard(W, R, r)
+                    assert [len(p) for p in pt] == shard_level_sizes([W - 1] + [W] * (N - 2), ws, we)
+                    for g in (0, 1, 5, 15):
+                        full = list(range(g * (N - 1)))
+                        exp = O.lp_guess_shard(full if g else None, N - 1, R, r)
+                        lo, hi = guess_shard(g, R, r)
+                        assert (exp or []) == full[lo * (N - 1): hi * (N - 1)]
