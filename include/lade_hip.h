@@ -197,11 +197,16 @@ int lade_window_roll(int32_t* window, int32_t wcap, int32_t* ctl, const int32_t*
  * reference's all_old_tokens]) -> lookup of the next step's candidates into `guess` / ctl[G] -> ctl update
  * (P, lst_token, lst_pos, kv-commit triple, hits, step).
  * record = {max_hit, n_accept, finished_by_eos, g_next, P_next, max_hit_idx, first_guess, -, hits[gs]}.
- * eos < 0 disables the EOS scan; the scan follows lade/decoding.py:1167-1177. */
+ * eos < 0 disables the EOS scan; the scan follows lade/decoding.py:1167-1177.
+ * Sampling (lade/decoding.py:137-692): the rejection-sampling verify runs on the host (it consumes the python
+ * and torch RNG streams in the reference's order); its result is passed as forced = {max_hit, max_hit_idx,
+ * hits[gs]} (device) and replaces the greedy verify; level_override[W] (device, -1 = keep) carries the
+ * filter_window() replacements of EOS tokens in the newest window level.  Both are null for greedy. */
 int lade_greedy_post_step(int32_t* ctl, int32_t* window, int32_t wcap, int32_t* pool_tok, int32_t* pool_cnt,
                           int32_t V, int32_t W, int32_t N, int32_t G, const int32_t* am, int32_t n_inp,
                           int32_t* guess, int32_t T_step, int32_t cand_rows, int32_t phase, int32_t pool_from_prompt,
-                          int32_t* tail, int32_t eos, int32_t* record, void* stream);
+                          int32_t* tail, int32_t eos, const int32_t* forced, const int32_t* level_override,
+                          int32_t* record, void* stream);
 
 /* lookahead parallelism: rank-local verify + record packing, then (after the host's RCCL all-gather of
  * rec_words int32 per rank) the deterministic reduction every rank applies (same phases as above).

@@ -315,14 +315,15 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(const void* logits, i
 
 // EOS scan + POOL_FROM_PROMPT appends (lade/decoding.py:1167-1177); returns n_accept, sets *finished
 __device__ int accept_scan(const int32_t* hits, int max_hit, int eos, int pool_from_prompt, int32_t* tail, int32_t* ng,
-                           int32_t* pool_tok, int32_t* pool_cnt, int V, int G, int N, int* finished) {
+                           int32_t* pool_tok, int32_t* pool_cnt, int V, int G, int N, int sample_mode, int* finished) {
     const int lane = threadIdx.x;
     const int gs = N - 1;
-    const int new_lst = hits[max_hit];
     int n_accept = max_hit + 1;
     *finished = 0;
     for (int hit_idx = 0; hit_idx <= max_hit; ++hit_idx) {
         if (eos >= 0 && hits[hit_idx] == eos) { n_accept = hit_idx + 1; *finished = 1; break; }
+        // greedy appends hits[max_hit] for every accepted index (decoding.py:1175), sampling hits[hit_idx] (:601)
+        const int new_lst = sample_mode ? hits[hit_idx] : hits[max_hit];
         if (pool_from_prompt) {
             // all_old_tokens.append(hits[max_hit]); append_new_generated_pool(all_old_tokens[-N:])
             __syncthreads();
@@ -347,7 +348,8 @@ __device__ int accept_scan(const int32_t* hits, int max_hit, int eos, int pool_f
 __global__ __launch_bounds__(64) void greedy_post_step_kernel(int32_t* ctl, int32_t* window, int wcap, int32_t* pool_tok,
                                                               int32_t* pool_cnt, int V, int W, int N, int G, const int32_t* am,
                                                               int n_inp, int32_t* guess, int T_step, int cand_rows, int phase,
-                                                              int pool_from_prompt, int32_t* tail, int eos, int32_t* record) {
+                                                              int pool_from_prompt, int32_t* tail, int eos, const int32_t* forced,
+                                                              const int32_t* level_override, int32_t* record) {
     __shared__ int32_t tup[LADE_MAX_LEVEL];
     __shared__ int32_t hits[LADE_MAX_LEVEL];
     __shared__ int32_t ng[LADE_MAX_LEVEL + 1];
@@ -363,13 +365,27 @@ __global__ __launch_bounds__(64) void greedy_post_step_kernel(int32_t* ctl, int3
     const int32_t* inp_am = am + 1;
     const int32_t* am_guess = am + 1 + n_inp;
     int max_hit = 0, max_hit_idx = 0;
-    if (phase == 2) {
-        verify_greedy(first_guess, guess, am_guess, g, gs, &max_hit, &max_hit_idx, hits);
+    // `forced` = {max_hit, max_hit_idx, hits[gs]} decided on the host (sampling verify, lade/decoding.py:484-540)
+    if (forced) {
+        max_hit = forced[0];
+        max_hit_idx = forced[1];
+        if (lane < gs) hits[lane] = forced[2 + lane];
         __syncthreads();
+    }
+    if (phase == 2) {
+        if (!forced) {
+            verify_greedy(first_guess, guess, am_guess, g, gs, &max_hit, &max_hit_idx, hits);
+            __syncthreads();
+        }
         pool_insert_window(pool_tok, pool_cnt, V, G, gs, lst_token, window, wcap, inp_am, W, N, tup);
         window_roll(window, wcap, ctl, inp_am, W, N);
+        if (level_override) {                                   // filter_window (lade/decoding.py:131-135, :578-580)
+            for (int i = lane; i < W; i += 64)
+                if (level_override[i] >= 0) window[(N - 2) * wcap + i] = level_override[i];
+            __syncthreads();
+        }
     } else {
-        if (lane < gs) hits[lane] = lane == 0 ? first_guess : 0;
+        if (!forced && lane < gs) hits[lane] = lane == 0 ? first_guess : 0;
         __syncthreads();
         if (phase == 0) window_fill_first(window, wcap, ctl, inp_am, n_inp);
         else window_fill(window, wcap, ctl, fill_level, inp_am, n_inp);
@@ -377,7 +393,7 @@ __global__ __launch_bounds__(64) void greedy_post_step_kernel(int32_t* ctl, int3
     const int kvcache_len = P + n_input;                 // lade/decoding.py:1154-1165
     const int new_lst = hits[max_hit];
     int finished;
-    const int n_accept = accept_scan(hits, max_hit, eos, pool_from_prompt, tail, ng, pool_tok, pool_cnt, V, G, N, &finished);
+    const int n_accept = accept_scan(hits, max_hit, eos, pool_from_prompt, tail, ng, pool_tok, pool_cnt, V, G, N, forced != nullptr, &finished);
     // next step's candidates (lade/decoding.py:948-954): only once the window is full
     const bool window_full = phase == 2 || ctl[LADE_CTL_FILL_LEVEL] >= N - 2;
     int g_next = 0;
@@ -594,7 +610,7 @@ extern "C" int lade_argmax_rows(const void* logits, int64_t ld, int32_t rows, in
 extern "C" int lade_greedy_post_step(int32_t* ctl, int32_t* window, int32_t wcap, int32_t* pool_tok, int32_t* pool_cnt, int32_t V,
                                      int32_t W, int32_t N, int32_t G, const int32_t* am, int32_t n_inp, int32_t* guess, int32_t T_step,
                                      int32_t cand_rows, int32_t phase, int32_t pool_from_prompt, int32_t* tail, int32_t eos,
-                                     int32_t* record, void* stream) {
+                                     const int32_t* forced, const int32_t* level_override, int32_t* record, void* stream) {
     const int gs = N - 1;
     POOL_ARGS_OK("lade_greedy_post_step");
     LADE_REQUIRE(ctl && window && am && guess && record && W > 0 && W + N - 3 <= wcap && N >= 3 && N <= LADE_MAX_LEVEL && T_step > 0 && cand_rows >= 0 &&
@@ -602,7 +618,7 @@ extern "C" int lade_greedy_post_step(int32_t* ctl, int32_t* window, int32_t wcap
                  LADE_E_ARG, "lade_greedy_post_step: W=%d N=%d wcap=%d T=%d phase=%d n_inp=%d", W, N, wcap, T_step, phase, n_inp);
     LADE_REQUIRE(!pool_from_prompt || tail, LADE_E_ARG, "lade_greedy_post_step: POOL_FROM_PROMPT needs the tail buffer");
     hipLaunchKernelGGL(greedy_post_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctl, window, wcap, pool_tok, pool_cnt, V, W, N, G,
-                       am, n_inp, guess, T_step, cand_rows, phase, pool_from_prompt, tail, eos, record);
+                       am, n_inp, guess, T_step, cand_rows, phase, pool_from_prompt, tail, eos, forced, level_override, record);
     return check_launch("lade_greedy_post_step");
 }
 

@@ -153,7 +153,7 @@ class LookaheadDecoder:
         logits = e.forward(st.ids, st.pos, mask, self._graph_sel[gcap], 1 + W + cand_rows, dyn_P=st.ctl, n_splits=self._graph_splits[gcap])
         ops.argmax_rows(logits, out=st.am)
         call("lade_greedy_post_step", ptr(st.ctl), ptr(st.window), st.wcap, ptr(st.pool_tok), ptr(st.pool_cnt), st.V, W, N, G,
-             ptr(st.am), W, ptr(st.guess), T, cand_rows, 2, int(self.pool_from_prompt), ptr(st.tail), self.eos, ptr(st.record))
+             ptr(st.am), W, ptr(st.guess), T, cand_rows, 2, int(self.pool_from_prompt), ptr(st.tail), self.eos, None, None, ptr(st.record))
         ops.kv_commit(e.kv, 0, 0, 0, ctl=st.ctl)
         st.record_host.copy_(st.record, non_blocking=True)
 
@@ -252,7 +252,7 @@ class LookaheadDecoder:
         logits = e.forward(st.ids, st.pos, mask, st.sel, n_sel)
         ops.argmax_rows(logits, out=st.am)
         call("lade_greedy_post_step", ptr(st.ctl), ptr(st.window), st.wcap, ptr(st.pool_tok), ptr(st.pool_cnt), st.V, W, N, G,
-             ptr(st.am), n_inp, ptr(st.guess), T, cand_rows, phase, int(self.pool_from_prompt), ptr(st.tail), self.eos, ptr(st.record))
+             ptr(st.am), n_inp, ptr(st.guess), T, cand_rows, phase, int(self.pool_from_prompt), ptr(st.tail), self.eos, None, None, ptr(st.record))
         ops.kv_commit(e.kv, 0, 0, 0, ctl=st.ctl)
         rec = st.read_record()
         self.steps += 1
@@ -279,6 +279,108 @@ class LookaheadDecoder:
             if keep_trace:
                 trace.append(info)
             if self.finished_by_eos or len(self.tokens) >= max_length:      # stopping criteria (:1204-1219)
+                break
+        generated = min(len(self.tokens), max_length) - len(self.prompt)
+        out = GenOut(tokens=self.tokens[:max_length], steps=self.steps, generated=generated, trace=trace)
+        if CONFIG_MAP.get("DEBUG", 0):
+            CONFIG_MAP.setdefault("log", []).append([generated, self.steps, round(generated / self.steps, 2)])
+        return out
+
+
+    # ---- sampling ------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def sample(self, prompt: Sequence[int], max_length: int, warp=None, eos_token_id: Optional[int] = None,
+               rng: Optional[random.Random] = None, torch_gen: Optional[torch.Generator] = None, keep_trace: bool = False) -> GenOut:
+        """`jacobi_sample_multilevel` (lade/decoding.py:137-692), single GPU (the reference has no LP here).
+
+        The model step, input assembly, pool and window stay on the GPU; what runs on the host is exactly what
+        consumes the reference's RNG streams, in the reference's order: `rng.random()` once per verification
+        trial and `torch.multinomial` (CPU generator `torch_gen`) for every sampled token (:484-540), plus the
+        `filter_window` draws (:578-580).  `warp(scores)` maps fp32 logits rows [r, V] to warped logits (the
+        Temperature / TopK / TopP warpers the reference admits, :375-377)."""
+        from .sampling import sample_verify
+        e, st = self.e, self.st
+        W, N, G, gs = self.W, self.N, self.G, self.gs
+        rng = rng if rng is not None else random
+        warp = warp if warp is not None else (lambda x: x)
+        self.start(prompt, eos_token_id, rng)
+        all_old_tokens = list(self.prompt)
+        set_token = lambda: rng.choice(all_old_tokens)
+        forced = torch.zeros(2 + cabi.MAX_LEVEL, dtype=torch.int32, device=e.device)
+        override = torch.zeros(W, dtype=torch.int32, device=e.device)
+        multinomial = lambda p: int(torch.multinomial(p, num_samples=1, generator=torch_gen).item())
+        trace: List[dict] = []
+        while True:
+            prompt_l, P, g, fill_level = self.prompt, self.P, self.g, self.fill_level
+            if self.steps == 0:
+                phase, n_input = 0, len(prompt_l)
+                ids_h = prompt_l + self.window0
+                total = len(ids_h)
+                last_len = min(total, max(e.max_T, len(self.window0) + 1))
+                done = 0
+                while total - done > last_len:
+                    n = min(e.max_T, total - last_len - done)
+                    st.ids[:n].copy_(torch.tensor(ids_h[done:done + n], dtype=torch.int32))
+                    st.pos[:n].copy_(torch.arange(done, done + n, dtype=torch.int32))
+                    e.forward(st.ids, st.pos, StepMask(T=n, P=done, is_prefill=True), st.sel, 0)
+                    done += n
+                T = total - done
+                st.ids[:T].copy_(torch.tensor(ids_h[done:], dtype=torch.int32))
+                st.pos[:T].copy_(torch.arange(done, total, dtype=torch.int32))
+                mask = StepMask(T=T, P=done, is_prefill=True)
+                n_inp, cand_rows = len(self.window0), 0
+                n_input = len(prompt_l) - done
+            else:
+                phase = 2 if fill_level >= N - 2 else 1
+                n_input = 1
+                ls = self._level_sizes(fill_level)
+                cand_rows = g * gs if phase == 2 else 0
+                mask = StepMask.from_levels(n_input, ls, cand_rows, gs, P)
+                T = mask.T
+                call("lade_build_inputs", None, None, n_input, ptr(st.window), st.wcap, ptr(st.ctl), min(fill_level, N - 2), 0, -1,
+                     ptr(st.guess), g if phase == 2 else 0, gs, cand_rows, ptr(st.ids), ptr(st.pos), None)
+                n_inp = ls[-1]
+            rows = [n_input - 1] + list(range(T - cand_rows - n_inp, T - cand_rows)) + list(range(T - cand_rows, T))
+            n_sel = self._set_sel(rows)
+            logits = e.forward(st.ids, st.pos, mask, st.sel, n_sel).float()        # logits.float(), modeling_llama.py:1544
+            ops.argmax_rows(logits, out=st.am)                                        # window levels are filled by argmax (:459, :545)
+            next_scores = warp(logits[0:1])
+            max_hit, max_hit_idx = 0, 0
+            if phase == 2 and g > 0:
+                guess_tokens = st.guess[:g * gs].tolist()
+                probs_next = torch.softmax(next_scores, dim=-1)[0].cpu()
+                guess_probs = torch.softmax(warp(logits[1 + n_inp:1 + n_inp + g * gs]), dim=-1)
+                hits, max_hit_idx = sample_verify(probs_next, lambda row: guess_probs[row].cpu(), guess_tokens, gs, rng, multinomial)
+                max_hit = len(hits) - 1
+            else:
+                probs = torch.softmax(next_scores, dim=-1)[0].cpu()
+                hits = [multinomial(probs)]
+            level_override = None
+            if phase == 2 and self.eos >= 0:                                      # filter_window on the new level (:578-580)
+                new_results = st.am[1:1 + W].tolist()
+                repl = [-1] * W
+                for i, tok in enumerate(new_results):
+                    if tok == self.eos:
+                        repl[i] = set_token()
+                if any(x >= 0 for x in repl):
+                    override.copy_(torch.tensor(repl, dtype=torch.int32))
+                    level_override = override
+            forced.copy_(torch.tensor([max_hit, max_hit_idx] + hits + [0] * (cabi.MAX_LEVEL - len(hits)), dtype=torch.int32))
+            call("lade_greedy_post_step", ptr(st.ctl), ptr(st.window), st.wcap, ptr(st.pool_tok), ptr(st.pool_cnt), st.V, W, N, G,
+                 ptr(st.am), n_inp, ptr(st.guess), T, cand_rows, phase, int(self.pool_from_prompt), ptr(st.tail), self.eos,
+                 ptr(forced), ptr(level_override), ptr(st.record))
+            ops.kv_commit(e.kv, 0, 0, 0, ctl=st.ctl)
+            rec = st.read_record()
+            self.steps += 1
+            n_accept, eos_hit, self.g, self.P = rec[1], rec[2], rec[3], rec[4]
+            accepted = hits[:n_accept]
+            self.tokens += accepted
+            all_old_tokens += accepted
+            if phase != 2:
+                self.fill_level += 1
+            if keep_trace:
+                trace.append(dict(T=T, P_before=mask.P, max_hit=max_hit, max_hit_idx=max_hit_idx, accepted=list(accepted), phase=phase))
+            if eos_hit or len(self.tokens) >= max_length:
                 break
         generated = min(len(self.tokens), max_length) - len(self.prompt)
         out = GenOut(tokens=self.tokens[:max_length], steps=self.steps, generated=generated, trace=trace)

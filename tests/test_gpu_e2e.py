@@ -109,3 +109,50 @@ def test_graph_mode_bf16_equals_eager_mode():
     b = LookaheadDecoder(eng, 15, 5, 15, use_graph=True).greedy(prompt, len(prompt) + 60, rng=random.Random(1), keep_trace=True)
     assert a.tokens == b.tokens and a.steps == b.steps
     assert [t["max_hit"] for t in a.trace] == [t["max_hit"] for t in b.trace]
+
+
+def test_sampling_fp32_identical_tokens_vs_reference():
+    """jacobi_sample_multilevel parity: same python/torch RNG order, probabilities from the HIP step in fp32 ->
+    the reference's sampled token ids and step counts (temperature / top-k / top-p runs)."""
+    from lookaheaddecoding_amd.decoding import LookaheadDecoder
+    from lookaheaddecoding_amd.sampling import make_warper
+    d = load("e2e_sample.json")
+    for run in d["runs"]:
+        cfg, w, eng = make_engine(run, torch.float32)
+        dec = LookaheadDecoder(eng, run["W"], run["N"], run["G"])
+        torch.manual_seed(run["seed"])
+        out = dec.sample(run["prompt"], run["max_length"], warp=make_warper(**run["warp"]), rng=random.Random(run["seed"]),
+                         torch_gen=torch.default_generator)
+        assert out.tokens == run["tokens"], run["warp"]
+        assert out.steps == run["steps"]
+
+
+def test_sampling_logits_within_tolerance_bf16():
+    """north_star: 'sampling logits match within a stated fp tolerance' - bf16 step logits vs the fp32 oracle on
+    the same (bf16-rounded) weights, steady step with candidates: atol 6e-2 on logits of magnitude ~1."""
+    from lookaheaddecoding_amd.ops import StepMask
+    cfg, w, eng = make_engine("tiny-d128", torch.bfloat16, 2, 0.05)
+    wq = {k: v.bfloat16().float() for k, v in w.items()}
+    model = O.OracleLlama(cfg, wq)
+    torch.manual_seed(0)
+    prompt = torch.randint(3, cfg["vocab"], (40,)).tolist()
+    W, N, gs, g = 15, 5, 4, 6
+    past = [[int(x) for x in torch.randint(3, cfg["vocab"], (W - 1,))]] + [[int(x) for x in torch.randint(3, cfg["vocab"], (W,))] for _ in range(N - 2)]
+    guess = [int(x) for x in torch.randint(3, cfg["vocab"], (g * gs,))]
+    cache = model.new_cache()
+    import numpy as np
+    P = len(prompt)
+    vis = np.tril(np.ones((P, P), dtype=bool))
+    model.forward(prompt, list(range(P)), vis, cache)
+    ref = O.model_step(model, cache, [7], [P], past, guess, N - 2, gs)
+    # engine: prefill then the same step
+    ids = torch.tensor(prompt, dtype=torch.int32, device="cuda"); pos = torch.arange(P, dtype=torch.int32, device="cuda")
+    eng.forward(ids, pos, StepMask(T=P, P=0, is_prefill=True), torch.zeros(1, dtype=torch.int32, device="cuda"), 0)
+    lay = ref.layout
+    T = lay.T
+    sel = torch.arange(T, dtype=torch.int32, device="cuda")
+    logits = eng.forward(torch.tensor(lay.ids, dtype=torch.int32, device="cuda"), torch.tensor(lay.positions, dtype=torch.int32, device="cuda"),
+                         StepMask.from_levels(1, lay.level_sizes, lay.lguess, gs, P), sel, T).float().cpu()
+    assert torch.allclose(logits[0], ref.out_logits, atol=6e-2, rtol=5e-2)
+    assert torch.allclose(logits[T - lay.lguess - W:T - lay.lguess], ref.inp_logits, atol=6e-2, rtol=5e-2)
+    assert torch.allclose(logits[T - lay.lguess:], ref.guess_logits, atol=6e-2, rtol=5e-2)
