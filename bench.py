@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--prompt-len", type=int, default=2048)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--no-graph", action="store_true", help="run steady steps eagerly instead of replaying the captured hipGraph")
+    ap.add_argument("--force-lp", action="store_true", help="run the lookahead-parallel code path even with one rank (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-steps", type=int, default=3)
     return ap.parse_args()
@@ -134,8 +135,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    use_lp = world > 1 or args.force_lp
+    if use_lp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from lookaheaddecoding_amd import ops
@@ -156,38 +160,43 @@ def main():
     eng = StepEngine(cfg, weights, dtype=dtype, device=dev, max_seq=max_seq, max_T=512)
     del weights
     lp = None
-    if world > 1:
+    if use_lp:
         from lookaheaddecoding_amd.parallel import LPContext
         lp = LPContext(rank=rank, world=world)
-    dec = LookaheadDecoder(eng, W, N, G, lp=lp, use_graph=not args.no_graph and world == 1)
+    dec = LookaheadDecoder(eng, W, N, G, lp=lp, use_graph=not args.no_graph and not use_lp)
     prompt = torch.randint(3, cfg["vocab"], (args.prompt_len,), generator=torch.Generator().manual_seed(123)).tolist()
 
     def sync():
-        if world > 1:
+        if use_lp:
             dist.barrier()
         torch.cuda.synchronize()
 
-    dec.start(prompt, rng=random.Random(1))
+    run = dec
+    if use_lp:
+        from lookaheaddecoding_amd.parallel import LPRunner
+        run = LPRunner(dec)
+    run.start(prompt, rng=random.Random(1))
     for _ in range(N - 1):                       # prefill + window fill: setup, untimed
-        dec.step()
+        run.step()
     for _ in range(args.warmup):
-        dec.step()
+        run.step()
     sync()
-    tok0 = len(dec.tokens)
+    tok0 = len(run.tokens)
     t0 = time.perf_counter()
     infos = []
     for _ in range(args.steps):
-        infos.append(dec.step())
+        infos.append(run.step())
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_lp:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    new_tokens = len(dec.tokens) - tok0
+    new_tokens = len(run.tokens) - tok0
     S = new_tokens / args.steps
-    avg_T = sum(i["T"] for i in infos) / len(infos)
-    P_end = dec.P
+    Ts = [i["T"] for i in infos if i.get("T")]
+    avg_T = (sum(Ts) / len(Ts)) if Ts else float((N - 1) * W)
+    P_end = run.P
 
     out = None
     if rank == 0:
@@ -215,13 +224,13 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (random-init weights, random prompt ids)",
             "config": {"workload": f"{args.model}-shape ({cfg['layers']}L) {args.dtype} greedy lookahead, 1 sequence, prompt {args.prompt_len}, "
-                                   f"W={W} N={N} G={G}, cold regime (untied random weights)", "parallelism": f"lp{world}" if world > 1 else "single",
+                                   f"W={W} N={N} G={G}, cold regime (untied random weights)", "parallelism": f"lp{world}" if use_lp else "single",
                        "tokens_per_step_T": round(avg_T, 1), "kv_len_end": P_end, "hipgraph": bool(dec.use_graph)},
             "step_compression": round(S, 3), "steps_per_s": round(args.steps / elapsed, 2),
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_lp:
         dist.barrier()
         dist.destroy_process_group()
 

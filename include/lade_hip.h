@@ -238,6 +238,26 @@ int lade_silu_mul(const void* gu, void* out, int32_t rows, int32_t inter, int32_
 int lade_gather_rows(const void* src, const int32_t* idx, void* dst, int32_t rows, int32_t width, int32_t elem_bytes,
                      int32_t src_rows, void* stream);
 
+/* ---- skinny weight-streaming GEMM -------------------------------------
+ * C[M,N] = A[M,K] . W[N,K]^T for the projections of a decode step (M = T <= ~256 rows), bf16 / f16, fp32 accumulate.
+ * n_split == 1: writes C (model dtype).  n_split > 1: writes fp32 partials Cpart[n_split][M][N] (summed in split
+ * order - deterministic - by lade_splitk_reduce).  bn = weight rows per work-group (64..256), mb = 32-row activation
+ * blocks per work-group (2: 64 rows, 4: 128 rows, 0: by M).  K % 64 == 0. */
+int lade_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, float* Cpart,
+                     int32_t M, int32_t N, int32_t K, int32_t n_split, int32_t bn, int32_t mb, int32_t dtype, void* stream);
+/* consumers that take a GEMM output as n_parts fp32 split-K partials [n_parts][rows][width] (part_stride elements
+ * apart), sum them in split order and round once to the model dtype - so the split-K GEMM needs no reduce pass */
+int lade_add_rmsnorm_parts(void* x, const float* parts, int32_t n_parts, int64_t part_stride, const void* weight, void* y,
+                           int32_t rows, int32_t hidden, float eps, int32_t dtype, void* stream);
+int lade_silu_mul_parts(const float* parts, int32_t n_parts, int64_t part_stride, void* out, int32_t rows, int32_t inter,
+                        int32_t dtype, void* stream);
+int lade_rope_kv_append_parts(const float* parts, int32_t n_parts, int64_t part_stride, void* q_out, const int32_t* positions,
+                              const void* cos_tab, const void* sin_tab, void* k_cache, void* vt_cache, int32_t T, int32_t P,
+                              const int32_t* dyn_P, int32_t H, int32_t Hkv, int32_t d, int32_t S_max, int32_t max_pos,
+                              int32_t dtype, void* stream);
+int lade_splitk_reduce(const float* part, void* C, int64_t ldc, int32_t M, int32_t N, int32_t n_split, int32_t dtype,
+                       void* stream);
+
 /* ---- misc ------------------------------------------------------------------------------- */
 int lade_version(void);
 const char* lade_last_error_string(void);

@@ -76,6 +76,34 @@ template <> __device__ __forceinline__ u32x4 repack<F16>(const float* f) {
 template <> __device__ __forceinline__ u32x4 repack<F32>(const float* f) {
     return u32x4{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
 }
+// Sum of the n_parts fp32 split-K partials of a GEMM output (fixed order: deterministic), rounded once to the
+// storage type like a library GEMM's output would be.  part_stride = elements between consecutive partials.
+template <typename T, int N>
+__device__ __forceinline__ void load_parts(const float* parts, int n_parts, size_t part_stride, size_t idx, float* out) {
+#pragma unroll
+    for (int e = 0; e < N; ++e) out[e] = 0.f;
+    // 4 partials per round so that all their loads are in flight together; summation order stays 0,1,2,...
+    for (int s0 = 0; s0 < n_parts; s0 += 4) {
+        float4 v[4][N / 4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* p = parts + (size_t)min(s0 + j, n_parts - 1) * part_stride + idx;
+#pragma unroll
+            for (int e = 0; e < N / 4; ++e) v[j][e] = *reinterpret_cast<const float4*>(p + 4 * e);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (s0 + j < n_parts) {
+#pragma unroll
+                for (int e = 0; e < N / 4; ++e) {
+                    out[4 * e] += v[j][e].x; out[4 * e + 1] += v[j][e].y; out[4 * e + 2] += v[j][e].z; out[4 * e + 3] += v[j][e].w;
+                }
+            }
+    }
+#pragma unroll
+    for (int e = 0; e < N; ++e) { const typename St<T>::S sv = stf<T>(out[e]); out[e] = ldf<T>(&sv, 0); }
+}
+
 // value after one rounding to the storage type
 template <typename T> __device__ __forceinline__ float rnd_st(float f) { typename St<T>::S s = stf<T>(f); return ldf<T>(&s, 0); }
 
@@ -83,7 +111,8 @@ template <typename T> __device__ __forceinline__ float rnd_st(float f) { typenam
 // One block per row, the row lives in registers (<= CH 16-byte chunks per thread): one HBM pass.
 template <typename T, bool ADD, int CH>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(typename St<T>::S* x, const typename St<T>::S* r, const typename St<T>::S* w,
-                                                      typename St<T>::S* y, int hidden, float eps) {
+                                                      typename St<T>::S* y, int hidden, float eps, const float* parts, int n_parts,
+                                                      size_t part_stride) {
     constexpr int N = Vec<T>::N;
     __shared__ float sm[8];
     const size_t base = (size_t)blockIdx.x * hidden;
@@ -97,7 +126,8 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(typename St<T>::S* x, cons
             unpack<T>(*reinterpret_cast<const u32x4*>(x + base + (size_t)i * N), v[c]);
             if (ADD) {
                 float rr[N];
-                unpack<T>(*reinterpret_cast<const u32x4*>(r + base + (size_t)i * N), rr);
+                if (parts) load_parts<T, N>(parts, n_parts, part_stride, base + (size_t)i * N, rr);
+                else unpack<T>(*reinterpret_cast<const u32x4*>(r + base + (size_t)i * N), rr);
 #pragma unroll
                 for (int e = 0; e < N; ++e) v[c][e] = rnd_st<T>(v[c][e] + rr[e]);
                 *reinterpret_cast<u32x4*>(x + base + (size_t)i * N) = repack<T>(v[c]);
@@ -123,14 +153,20 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(typename St<T>::S* x, cons
 
 // out[r][i] = silu(gu[r][i]) * gu[r][inter+i], rounded like torch: act(gate) -> dtype, then * up -> dtype
 template <typename T>
-__global__ __launch_bounds__(256) void silu_mul_kernel(const typename St<T>::S* gu, typename St<T>::S* out, int inter) {
+__global__ __launch_bounds__(256) void silu_mul_kernel(const typename St<T>::S* gu, typename St<T>::S* out, int inter, const float* parts,
+                                                       int n_parts, size_t part_stride) {
     constexpr int N = Vec<T>::N;
     const size_t rb = (size_t)blockIdx.y * 2 * inter;
     const int i = (blockIdx.x * blockDim.x + threadIdx.x) * N;
     if (i >= inter) return;
     float g[N], u[N], o[N];
-    unpack<T>(*reinterpret_cast<const u32x4*>(gu + rb + i), g);
-    unpack<T>(*reinterpret_cast<const u32x4*>(gu + rb + inter + i), u);
+    if (parts) {
+        load_parts<T, N>(parts, n_parts, part_stride, rb + i, g);
+        load_parts<T, N>(parts, n_parts, part_stride, rb + inter + i, u);
+    } else {
+        unpack<T>(*reinterpret_cast<const u32x4*>(gu + rb + i), g);
+        unpack<T>(*reinterpret_cast<const u32x4*>(gu + rb + inter + i), u);
+    }
 #pragma unroll
     for (int e = 0; e < N; ++e) o[e] = rnd_st<T>(g[e] / (1.f + __expf(-g[e]))) * u[e];
     *reinterpret_cast<u32x4*>(out + (size_t)blockIdx.y * inter + i) = repack<T>(o);
@@ -181,13 +217,14 @@ using namespace lade;
     }
 
 template <bool ADD>
-static int launch_rmsnorm(void* x, const void* r, const void* weight, void* y, int rows, int hidden, float eps, int dtype, hipStream_t st) {
+static int launch_rmsnorm(void* x, const void* r, const void* weight, void* y, int rows, int hidden, float eps, int dtype, hipStream_t st,
+                          const float* parts = nullptr, int n_parts = 0, size_t part_stride = 0) {
     const int nvec_bytes = dtype == LADE_F32 ? 4 : 8;
     LADE_REQUIRE(hidden % nvec_bytes == 0, LADE_E_ARG, "lade_rmsnorm: hidden=%d must be a multiple of %d", hidden, nvec_bytes);
     const int chunks = cdiv(hidden / nvec_bytes, 256);
     LADE_REQUIRE(chunks <= 8, LADE_E_LIMIT, "lade_rmsnorm: hidden=%d too large for the register-resident row", hidden);
 #define RMS_LAUNCH(CH) DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((rmsnorm_kernel<TT, ADD, CH>), dim3(rows), dim3(256), 0, st, (St<TT>::S*)x, \
-                                      (const St<TT>::S*)r, (const St<TT>::S*)weight, (St<TT>::S*)y, hidden, eps))
+                                      (const St<TT>::S*)r, (const St<TT>::S*)weight, (St<TT>::S*)y, hidden, eps, parts, n_parts, part_stride))
     if (chunks <= 1) { RMS_LAUNCH(1); } else if (chunks <= 2) { RMS_LAUNCH(2); } else if (chunks <= 4) { RMS_LAUNCH(4); } else { RMS_LAUNCH(8); }
 #undef RMS_LAUNCH
     return check_launch(ADD ? "lade_add_rmsnorm" : "lade_rmsnorm");
@@ -213,7 +250,7 @@ extern "C" int lade_silu_mul(const void* gu, void* out, int32_t rows, int32_t in
     hipStream_t st = (hipStream_t)stream;
     LADE_REQUIRE(inter % 8 == 0, LADE_E_ARG, "lade_silu_mul: inter=%d must be a multiple of 8", inter);
     const int per_thr = dtype == LADE_F32 ? 4 : 8;
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(silu_mul_kernel<TT>, dim3(cdiv(inter / per_thr, 256), rows), dim3(256), 0, st, (const St<TT>::S*)gu, (St<TT>::S*)out, inter));
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(silu_mul_kernel<TT>, dim3(cdiv(inter / per_thr, 256), rows), dim3(256), 0, st, (const St<TT>::S*)gu, (St<TT>::S*)out, inter, (const float*)nullptr, 0, (size_t)0));
     return check_launch("lade_silu_mul");
 }
 
@@ -230,4 +267,24 @@ extern "C" int lade_softmax_rows(const void* logits, int64_t ld, int32_t rows, i
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(softmax_rows_kernel<TT>, dim3(rows), dim3(256), 0, st, (const St<TT>::S*)logits, ld, V, 1.f / temperature, probs));
     return check_launch("lade_softmax_rows");
+}
+
+// split-K aware variants: the GEMM output arrives as n_parts fp32 partials [n_parts][rows][width]
+extern "C" int lade_add_rmsnorm_parts(void* x, const float* parts, int32_t n_parts, int64_t part_stride, const void* weight, void* y,
+                                      int32_t rows, int32_t hidden, float eps, int32_t dtype, void* stream) {
+    LADE_REQUIRE(x && parts && weight && y && rows >= 0 && hidden > 0 && n_parts >= 1, LADE_E_ARG, "lade_add_rmsnorm_parts: bad args");
+    LADE_REQUIRE(dtype != LADE_F32, LADE_E_DTYPE, "lade_add_rmsnorm_parts: 16-bit dtypes only");
+    if (rows == 0) return LADE_OK;
+    return launch_rmsnorm<true>(x, nullptr, weight, y, rows, hidden, eps, dtype, (hipStream_t)stream, parts, n_parts, (size_t)part_stride);
+}
+
+extern "C" int lade_silu_mul_parts(const float* parts, int32_t n_parts, int64_t part_stride, void* out, int32_t rows, int32_t inter, int32_t dtype,
+                                   void* stream) {
+    LADE_REQUIRE(parts && out && rows >= 0 && inter > 0 && inter % 8 == 0 && n_parts >= 1, LADE_E_ARG, "lade_silu_mul_parts: bad args");
+    LADE_REQUIRE(dtype != LADE_F32, LADE_E_DTYPE, "lade_silu_mul_parts: 16-bit dtypes only");
+    if (rows == 0) return LADE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(silu_mul_kernel<TT>, dim3(cdiv(inter / 8, 256), rows), dim3(256), 0, st, (const St<TT>::S*)nullptr, (St<TT>::S*)out, inter,
+                                             parts, n_parts, (size_t)part_stride));
+    return check_launch("lade_silu_mul_parts");
 }

@@ -36,7 +36,8 @@ __global__ __launch_bounds__(256) void rope_kv_append_kernel(typename Elem<T>::S
                                                              const typename Elem<T>::S* sin_tab,
                                                              typename Elem<T>::S* k_cache, typename Elem<T>::S* vt_cache,
                                                              int T_, int P, const int32_t* dyn_P, int H, int Hkv, int d,
-                                                             int S_max, int max_pos) {
+                                                             int S_max, int max_pos, const float* parts, int n_parts,
+                                                             size_t part_stride, typename Elem<T>::S* q_out) {
     typedef typename Elem<T>::S S;
     constexpr int VEC = 16 / sizeof(S);
     __shared__ S sm[64][32 + 2];
@@ -56,8 +57,27 @@ __global__ __launch_bounds__(256) void rope_kv_append_kernel(typename Elem<T>::S
                 const int h = idx / vph, i = (idx - h * vph) * VEC;
                 S* x = row + (size_t)h * d;
                 S x1[VEC], x2[VEC], c1[VEC], c2[VEC], s1[VEC], s2[VEC], o1[VEC], o2[VEC];
-                *reinterpret_cast<uint4*>(x1) = *reinterpret_cast<const uint4*>(x + i);
-                *reinterpret_cast<uint4*>(x2) = *reinterpret_cast<const uint4*>(x + i + half);
+                if (parts) {                       // qkv arrives as split-K fp32 partials: sum, round once to the dtype
+                    const size_t e0 = (size_t)t * row_w + (size_t)h * d + i;
+                    float a[VEC], b[VEC];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) { a[e] = 0.f; b[e] = 0.f; }
+                    for (int sp = 0; sp < n_parts; ++sp) {
+                        const float* pa = parts + sp * part_stride + e0;
+#pragma unroll
+                        for (int e = 0; e < VEC; e += 4) {
+                            const float4 va = *reinterpret_cast<const float4*>(pa + e);
+                            const float4 vb = *reinterpret_cast<const float4*>(pa + half + e);
+                            a[e] += va.x; a[e + 1] += va.y; a[e + 2] += va.z; a[e + 3] += va.w;
+                            b[e] += vb.x; b[e + 1] += vb.y; b[e + 2] += vb.z; b[e + 3] += vb.w;
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) { x1[e] = Elem<T>::st(a[e]); x2[e] = Elem<T>::st(b[e]); }
+                } else {
+                    *reinterpret_cast<uint4*>(x1) = *reinterpret_cast<const uint4*>(x + i);
+                    *reinterpret_cast<uint4*>(x2) = *reinterpret_cast<const uint4*>(x + i + half);
+                }
                 *reinterpret_cast<uint4*>(c1) = *reinterpret_cast<const uint4*>(c + i);
                 *reinterpret_cast<uint4*>(c2) = *reinterpret_cast<const uint4*>(c + i + half);
                 *reinterpret_cast<uint4*>(s1) = *reinterpret_cast<const uint4*>(s + i);
@@ -69,7 +89,7 @@ __global__ __launch_bounds__(256) void rope_kv_append_kernel(typename Elem<T>::S
                     o1[e] = Elem<T>::st(__fadd_rn(rnd<T>(__fmul_rn(a1, Elem<T>::ld(c1[e]))), rnd<T>(__fmul_rn(-a2, Elem<T>::ld(s1[e])))));
                     o2[e] = Elem<T>::st(__fadd_rn(rnd<T>(__fmul_rn(a2, Elem<T>::ld(c2[e]))), rnd<T>(__fmul_rn(a1, Elem<T>::ld(s2[e])))));
                 }
-                S* dst = h < H ? x : k_cache + ((size_t)(h - H) * S_max + P + t) * d;
+                S* dst = h < H ? (q_out ? q_out + ((size_t)t * H + h) * d : x) : k_cache + ((size_t)(h - H) * S_max + P + t) * d;
                 *reinterpret_cast<uint4*>(dst + i) = *reinterpret_cast<const uint4*>(o1);
                 *reinterpret_cast<uint4*>(dst + i + half) = *reinterpret_cast<const uint4*>(o2);
             }
@@ -95,9 +115,33 @@ __global__ __launch_bounds__(256) void rope_kv_append_kernel(typename Elem<T>::S
     const int t0 = (b / Hkv) * 64;
     const int nt = min(64, T_ - t0);
     const int d0 = dc * 32, nd = min(32, d - d0);
-    for (int idx = threadIdx.x; idx < 64 * 32; idx += blockDim.x) {
-        const int tt = idx >> 5, dd = idx & 31;
-        if (tt < nt && dd < nd) sm[tt][dd] = qkv[(size_t)(t0 + tt) * row_w + (size_t)(H + Hkv + kvh) * d + d0 + dd];
+    if (parts && nd == 32) {
+        for (int idx = threadIdx.x; idx < 64 * 8; idx += blockDim.x) {       // 8 float4 per 32-wide row
+            const int tt = idx >> 3, d4 = (idx & 7) * 4;
+            if (tt < nt) {
+                const size_t e0 = (size_t)(t0 + tt) * row_w + (size_t)(H + Hkv + kvh) * d + d0 + d4;
+                float4 a = *reinterpret_cast<const float4*>(parts + e0);
+                for (int sp = 1; sp < n_parts; ++sp) {
+                    const float4 b = *reinterpret_cast<const float4*>(parts + sp * part_stride + e0);
+                    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+                }
+                sm[tt][d4] = Elem<T>::st(a.x); sm[tt][d4 + 1] = Elem<T>::st(a.y); sm[tt][d4 + 2] = Elem<T>::st(a.z); sm[tt][d4 + 3] = Elem<T>::st(a.w);
+            }
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < 64 * 32; idx += blockDim.x) {
+            const int tt = idx >> 5, dd = idx & 31;
+            if (tt < nt && dd < nd) {
+                const size_t e0 = (size_t)(t0 + tt) * row_w + (size_t)(H + Hkv + kvh) * d + d0 + dd;
+                if (parts) {
+                    float a = 0.f;
+                    for (int sp = 0; sp < n_parts; ++sp) a += parts[sp * part_stride + e0];
+                    sm[tt][dd] = Elem<T>::st(a);
+                } else {
+                    sm[tt][dd] = qkv[e0];
+                }
+            }
+        }
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < 32 * 64; idx += blockDim.x) {
@@ -127,11 +171,11 @@ __global__ __launch_bounds__(256) void kv_commit_kernel(S* cache, int64_t layer_
 template <typename T>
 static int launch_rope(void* qkv, const int32_t* positions, const void* cos_tab, const void* sin_tab, void* k_cache,
                        void* vt_cache, int T_, int P, const int32_t* dyn_P, int H, int Hkv, int d, int S_max, int max_pos,
-                       hipStream_t st) {
+                       hipStream_t st, const float* parts = nullptr, int n_parts = 0, size_t part_stride = 0, void* q_out = nullptr) {
     typedef typename Elem<T>::S S;
     const int n_vblk = Hkv * cdiv(T_, 64) * cdiv(d, 32);
     hipLaunchKernelGGL(rope_kv_append_kernel<T>, dim3(T_ + n_vblk), dim3(256), 0, st, (S*)qkv, positions, (const S*)cos_tab,
-                       (const S*)sin_tab, (S*)k_cache, (S*)vt_cache, T_, P, dyn_P, H, Hkv, d, S_max, max_pos);
+                       (const S*)sin_tab, (S*)k_cache, (S*)vt_cache, T_, P, dyn_P, H, Hkv, d, S_max, max_pos, parts, n_parts, part_stride, (S*)q_out);
     return check_launch("lade_rope_kv_append");
 }
 
@@ -171,4 +215,20 @@ extern "C" int lade_kv_commit(void* cache, int64_t layer_stride, int64_t v_offse
     else
         hipLaunchKernelGGL(kv_commit_kernel<uint32_t>, dim3(L, Hkv), dim3(256), 0, st, (uint32_t*)cache, layer_stride, v_offset, Hkv, d, S_max, src, dst, cnt, ctl);
     return check_launch("lade_kv_commit");
+}
+
+// qkv arrives as n_parts fp32 split-K partials [n_parts][T][(H+2Hkv)*d]; the rotated q goes to q_out [T][H*d]
+extern "C" int lade_rope_kv_append_parts(const float* parts, int32_t n_parts, int64_t part_stride, void* q_out, const int32_t* positions,
+                                         const void* cos_tab, const void* sin_tab, void* k_cache, void* vt_cache, int32_t T, int32_t P,
+                                         const int32_t* dyn_P, int32_t H, int32_t Hkv, int32_t d, int32_t S_max, int32_t max_pos, int32_t dtype,
+                                         void* stream) {
+    LADE_REQUIRE(parts && q_out && positions && cos_tab && sin_tab && k_cache && vt_cache && n_parts >= 1, LADE_E_ARG, "lade_rope_kv_append_parts: null pointer");
+    LADE_REQUIRE(T > 0 && P >= 0 && P + T <= S_max && H > 0 && Hkv > 0 && d > 0 && (d / 2) % 8 == 0 && d <= 256 && max_pos > 0,
+                 LADE_E_ARG, "lade_rope_kv_append_parts: T=%d P=%d S_max=%d H=%d Hkv=%d d=%d", T, P, S_max, H, Hkv, d);
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case LADE_BF16: return launch_rope<BF16>(nullptr, positions, cos_tab, sin_tab, k_cache, vt_cache, T, P, dyn_P, H, Hkv, d, S_max, max_pos, st, parts, n_parts, (size_t)part_stride, q_out);
+        case LADE_F16: return launch_rope<F16>(nullptr, positions, cos_tab, sin_tab, k_cache, vt_cache, T, P, dyn_P, H, Hkv, d, S_max, max_pos, st, parts, n_parts, (size_t)part_stride, q_out);
+    }
+    LADE_REQUIRE(false, LADE_E_DTYPE, "lade_rope_kv_append_parts: dtype=%d", dtype);
 }

@@ -19,6 +19,7 @@ HIP extension or without a GPU.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -92,6 +93,13 @@ class StepEngine:
             self.part_ml = torch.empty(self.max_splits * self.H * max_T * 2, dtype=torch.float32, device=dev)
         else:
             self.part_o = self.part_ml = None
+        # hand-written weight-streaming GEMM (split-K partials consumed by the fused glue kernels) for steps of
+        # <= 128 tokens; every (N, K, row class) is timed against the library GEMM once and the faster one is kept
+        self.custom_gemm = dt != torch.float32 and os.environ.get("LADE_GEMM", "1") != "0" and self.d % 16 == 0 and self.hidden % 64 == 0 and self.inter % 64 == 0
+        self.gemm_cfg = {}
+        if self.custom_gemm:
+            self.ws_part = torch.empty(16 * 128 * max(qkv_w, 2 * self.inter, self.hidden), dtype=torch.float32, device=dev)
+            self.ws_q = torch.empty(max_T, self.H * self.d, dtype=dt, device=dev)
         try:
             self.n_cu = torch.cuda.get_device_properties(self.device.index).multi_processor_count
         except AssertionError:      # device count not initialised on this thread yet
@@ -112,6 +120,48 @@ class StepEngine:
             return 1
         return min(ops.choose_splits(self.H, self.H // self.Hkv, T, S_tot, self.n_cu), self.max_splits)
 
+    # ---- GEMM selection ---------------------------------------------------------------------------
+    def _tune(self, name: str, M: int):
+        """(mb, bn, n_split) of the split-K GEMM for projection `name` at a step of M rows, or None when the library
+        GEMM is faster.  Timed once per (projection, row class) on this GPU, rotating through the layers' weights so the
+        stream comes from HBM rather than from the Infinity Cache."""
+        mclass = 64 if M <= 64 else 128
+        key = (name, mclass)
+        if key in self.gemm_cfg:
+            return self.gemm_cfg[key]
+        ws = [lw[name] for lw in self.layers]
+        N, K = ws[0].shape
+        a = torch.randn(mclass if mclass == 128 else 60, K, device=self.device).to(self.dtype)
+        out = torch.empty(a.shape[0], N, dtype=self.dtype, device=self.device)
+        cands = []
+        for mb, bns in (((2, (128, 256)),) if mclass == 64 else ((4, (64, 128, 192, 256)),)):
+            for bn in bns:
+                nblk = (N + bn - 1) // bn
+                for S in sorted({max(1, round(self.n_cu / nblk)), max(1, round(self.n_cu * 2 / nblk)), max(1, round(self.n_cu * 3 / nblk))}):
+                    if 2 <= S <= 16 and K // 64 >= 2 * S:
+                        cands.append((mb, bn, S))
+
+        def time_it(fn, reps=8):
+            for i in range(2):
+                fn(i)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(reps):
+                fn(i)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        t_lib = time_it(lambda i: torch.matmul(a, ws[i % len(ws)].t(), out=out)) + 0.003      # + the consumer's extra read
+        best, t_best = None, t_lib
+        for (mb, bn, S) in cands:
+            t = time_it(lambda i: ops.gemm_parts(a, ws[i % len(ws)], self.ws_part, S, bn, mb))
+            if t < t_best:
+                best, t_best = (mb, bn, S), t
+        self.gemm_cfg[key] = best
+        return best
+
     # ---- one forward -----------------------------------------------------------------------------
     def forward(self, ids: torch.Tensor, pos: torch.Tensor, mask: StepMask, sel_rows: torch.Tensor, n_sel: int,
                 dyn_P: Optional[torch.Tensor] = None, n_splits: Optional[int] = None) -> torch.Tensor:
@@ -127,20 +177,51 @@ class StepEngine:
         if n_splits is None:
             n_splits = self.n_splits_for(T, P + T)
         ops.gather_rows(self.embed, ids, out=x, rows=T)
+        fused = self.custom_gemm and T <= 128
+        cfg_qkv = self._tune("wqkv", T) if fused else None
+        cfg_o = self._tune("wo", T) if fused else None
+        cfg_gu = self._tune("wgu", T) if fused else None
+        cfg_d = self._tune("wd", T) if fused else None
+        part = self.ws_part if fused else None
+        r_parts = 0                     # > 0: the pending residual branch lives in `part` as that many split-K partials
         for li, lw in enumerate(self.layers):
             if li == 0:
                 ops.rmsnorm(x, lw["ln1"], self.eps, out=h)
+            elif r_parts:
+                ops.add_rmsnorm_parts(x, part, r_parts, lw["ln1"], self.eps, out=h)   # x += mlp(prev); h = norm(x)
             else:
-                ops.add_rmsnorm(x, r, lw["ln1"], self.eps, out=h)          # x += mlp(prev); h = norm(x)
-            torch.matmul(h, lw["wqkv"].t(), out=qkv)
-            ops.rope_kv_append(qkv, pos, self.cos, self.sin, self.k_cache(li), self.vt_cache(li), P, H=H, Hkv=Hkv, d=d, dyn_P=dyn_P)
-            ops.attn_fwd(qkv, self.k_cache(li), self.vt_cache(li), mask, H=H, Hkv=Hkv, d=d, out=o, n_splits=n_splits,
+                ops.add_rmsnorm(x, r, lw["ln1"], self.eps, out=h)
+            if cfg_qkv:
+                ops.gemm_parts(h, lw["wqkv"], part, cfg_qkv[2], cfg_qkv[1], cfg_qkv[0])
+                qb = self.ws_q[:T]
+                ops.rope_kv_append_parts(part, cfg_qkv[2], qb, pos, self.cos, self.sin, self.k_cache(li), self.vt_cache(li), T, P, H=H, Hkv=Hkv, d=d, dyn_P=dyn_P)
+                q_in = qb
+            else:
+                torch.matmul(h, lw["wqkv"].t(), out=qkv)
+                ops.rope_kv_append(qkv, pos, self.cos, self.sin, self.k_cache(li), self.vt_cache(li), P, H=H, Hkv=Hkv, d=d, dyn_P=dyn_P)
+                q_in = qkv
+            ops.attn_fwd(q_in, self.k_cache(li), self.vt_cache(li), mask, H=H, Hkv=Hkv, d=d, out=o, n_splits=n_splits,
                          part_o=self.part_o, part_ml=self.part_ml, dyn_P=dyn_P)
-            torch.matmul(o, lw["wo"].t(), out=r)
-            ops.add_rmsnorm(x, r, lw["ln2"], self.eps, out=h)              # x += attn; h = norm(x)
-            torch.matmul(h, lw["wgu"].t(), out=gu)
-            ops.silu_mul(gu, out=a)
-            torch.matmul(a, lw["wd"].t(), out=r)
+            if cfg_o:
+                ops.gemm_parts(o, lw["wo"], part, cfg_o[2], cfg_o[1], cfg_o[0])
+                ops.add_rmsnorm_parts(x, part, cfg_o[2], lw["ln2"], self.eps, out=h)      # x += attn; h = norm(x)
+            else:
+                torch.matmul(o, lw["wo"].t(), out=r)
+                ops.add_rmsnorm(x, r, lw["ln2"], self.eps, out=h)
+            if cfg_gu:
+                ops.gemm_parts(h, lw["wgu"], part, cfg_gu[2], cfg_gu[1], cfg_gu[0])
+                ops.silu_mul_parts(part, cfg_gu[2], T, self.inter, out=a)
+            else:
+                torch.matmul(h, lw["wgu"].t(), out=gu)
+                ops.silu_mul(gu, out=a)
+            if cfg_d:
+                ops.gemm_parts(a, lw["wd"], part, cfg_d[2], cfg_d[1], cfg_d[0])
+                r_parts = cfg_d[2]
+            else:
+                torch.matmul(a, lw["wd"].t(), out=r)
+                r_parts = 0
+        if r_parts:                       # last layer's MLP output: fold the partials into r for the row-pruned tail
+            cabi.call("lade_splitk_reduce", cabi.ptr(part), cabi.ptr(r), r.stride(0), T, self.hidden, r_parts, cabi.dtype_code(r))
         if n_sel == 0:                                             # cache-filling chunk of a long prefill
             return None
         xs = ops.gather_rows(x, sel_rows, rows=n_sel)

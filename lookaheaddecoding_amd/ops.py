@@ -182,3 +182,45 @@ def softmax_rows(logits: torch.Tensor, temperature: float = 1.0) -> torch.Tensor
     probs = torch.empty(logits.shape, dtype=torch.float32, device=logits.device)
     call("lade_softmax_rows", ptr(logits), logits.stride(0), logits.shape[0], logits.shape[1], dtype_code(logits), float(temperature), ptr(probs))
     return probs
+
+
+def gemm_skinny(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, n_split: int = 1, bn: int = 128,
+                part: Optional[torch.Tensor] = None, mb: int = 0) -> torch.Tensor:
+    """out[M,N] = a[M,K] @ w[N,K]^T on the hand-written weight-streaming kernel (bf16 / f16)."""
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and a.stride(1) == 1 and w.stride(1) == 1
+    if out is None:
+        out = torch.empty(M, N, dtype=a.dtype, device=a.device)
+    if n_split > 1 and part is None:
+        part = torch.empty(n_split, M, N, dtype=torch.float32, device=a.device)
+    call("lade_gemm_skinny", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(out), out.stride(0), ptr(part), M, N, K, n_split, bn, mb, dtype_code(a))
+    if n_split > 1:
+        call("lade_splitk_reduce", ptr(part), ptr(out), out.stride(0), M, N, n_split, dtype_code(a))
+    return out
+
+
+def gemm_parts(a: torch.Tensor, w: torch.Tensor, part: torch.Tensor, n_split: int, bn: int, mb: int) -> None:
+    """split-K GEMM that leaves its result as n_split fp32 partials in `part` ([n_split][M][N], contiguous) for a
+    `*_parts` consumer kernel - no reduce pass."""
+    M, K = a.shape
+    N = w.shape[0]
+    call("lade_gemm_skinny", ptr(a), a.stride(0), ptr(w), w.stride(0), None, 0, ptr(part), M, N, K, n_split, bn, mb, dtype_code(a))
+
+
+def add_rmsnorm_parts(x: torch.Tensor, part: torch.Tensor, n_parts: int, w: torch.Tensor, eps: float, out: torch.Tensor) -> torch.Tensor:
+    rows, hidden = x.shape
+    call("lade_add_rmsnorm_parts", ptr(x), ptr(part), n_parts, rows * hidden, ptr(w), ptr(out), rows, hidden, eps, dtype_code(x))
+    return out
+
+
+def silu_mul_parts(part: torch.Tensor, n_parts: int, rows: int, inter: int, out: torch.Tensor) -> torch.Tensor:
+    call("lade_silu_mul_parts", ptr(part), n_parts, rows * 2 * inter, ptr(out), rows, inter, dtype_code(out))
+    return out
+
+
+def rope_kv_append_parts(part: torch.Tensor, n_parts: int, q_out: torch.Tensor, positions: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
+                         k_cache: torch.Tensor, vt_cache: torch.Tensor, T: int, P: int, *, H: int, Hkv: int, d: int,
+                         dyn_P: Optional[torch.Tensor] = None) -> None:
+    call("lade_rope_kv_append_parts", ptr(part), n_parts, T * (H + 2 * Hkv) * d, ptr(q_out), ptr(positions), ptr(cos), ptr(sin), ptr(k_cache),
+         ptr(vt_cache), T, P, ptr(dyn_P), H, Hkv, d, k_cache.shape[1], cos.shape[0], dtype_code(q_out))

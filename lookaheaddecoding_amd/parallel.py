@@ -146,32 +146,40 @@ class HipLPBackend:
         return t.tolist()
 
 
-def greedy_lp(dec, prompt: Sequence[int], max_length: int, eos_token_id: Optional[int] = None,
-              rng: Optional[random.Random] = None, keep_trace: bool = False, backend=None):
-    """Greedy lookahead decoding under lookahead parallelism (jacobi_greedy_search_multilevel with
-    DIST_WORKERS > 1, lade/decoding.py:697-1259).  `dec` supplies W, N, G and the LPContext; `backend`
-    defaults to the HIP backend."""
-    from .decoding import GenOut
-    lp: LPContext = dec.lp
-    R, r = lp.R, lp.rank
-    W, N, G = dec.W, dec.N, dec.G
-    gs = N - 1
-    if R > W:
-        raise ValueError(f"lookahead parallelism needs DIST_WORKERS ({R}) <= WINDOW_SIZE ({W})")
-    be = backend if backend is not None else HipLPBackend(dec)
-    rng = rng if rng is not None else random
-    prompt = [int(t) for t in prompt]
-    # every rank draws its own window, rank 0's is broadcast (lade/decoding.py:902-906)
-    window0 = [rng.choice(prompt) for _ in range(W + N - 3)]
-    window0 = be.broadcast_window(window0, lp)
-    eos = -1 if eos_token_id is None else int(eos_token_id)
-    be.begin(prompt, window0, eos)
-    all_rec = be.new_gather_buffer(R)
-    tokens = list(prompt)
-    steps, P, g, fill_level, n_input = 0, 0, 0, 0, len(prompt)
-    trace: List[dict] = []
-    while True:
-        phase = 0 if steps == 0 else (2 if fill_level >= N - 2 else 1)
+class LPRunner:
+    """Stepwise driver of greedy lookahead decoding under lookahead parallelism (start / step), used by
+    `greedy_lp` and by bench.py.  `dec` supplies W, N, G and the LPContext; `backend` defaults to the HIP backend."""
+
+    def __init__(self, dec, backend=None, all_gather=None):
+        self.dec = dec
+        self.lp: LPContext = dec.lp
+        # the collective is injectable so that tests can run several ranks inside one process
+        self.all_gather = all_gather if all_gather is not None else (lambda out, inp: dist.all_gather_into_tensor(out, inp, group=self.lp.group))
+        self.W, self.N, self.G = dec.W, dec.N, dec.G
+        if self.lp.R > self.W:
+            raise ValueError(f"lookahead parallelism needs DIST_WORKERS ({self.lp.R}) <= WINDOW_SIZE ({self.W})")
+        if getattr(dec, "pool_from_prompt", False):
+            raise NotImplementedError("POOL_FROM_PROMPT is not supported under lookahead parallelism yet")
+        self.be = backend if backend is not None else HipLPBackend(dec)
+
+    def start(self, prompt: Sequence[int], eos_token_id: Optional[int] = None, rng: Optional[random.Random] = None) -> None:
+        rng = rng if rng is not None else random
+        W, N = self.W, self.N
+        self.prompt = [int(t) for t in prompt]
+        # every rank draws its own window, rank 0's is broadcast (lade/decoding.py:902-906)
+        window0 = [rng.choice(self.prompt) for _ in range(W + N - 3)]
+        window0 = self.be.broadcast_window(window0, self.lp)
+        self.eos = -1 if eos_token_id is None else int(eos_token_id)
+        self.be.begin(self.prompt, window0, self.eos)
+        self.all_rec = self.be.new_gather_buffer(self.lp.R)
+        self.tokens = list(self.prompt)
+        self.steps, self.P, self.g, self.fill_level, self.n_input = 0, 0, 0, 0, len(self.prompt)
+        self.finished = False
+
+    def step(self) -> dict:
+        W, N, R, r = self.W, self.N, self.lp.R, self.lp.rank
+        fill_level = self.fill_level
+        phase = 0 if self.steps == 0 else (2 if fill_level >= N - 2 else 1)
         # level lengths before this step (see LookaheadDecoder._level_sizes)
         if fill_level == 0:
             level_lens = [W + N - 3]
@@ -180,25 +188,38 @@ def greedy_lp(dec, prompt: Sequence[int], max_length: int, eos_token_id: Optiona
         else:
             level_lens = [W + N - 3 - fill_level] + [W + N - 2 - fill_level] * fill_level
         c0, c1 = window_shard(level_lens[0] + 1, R, r)
-        glo, ghi = guess_shard(g, R, r) if phase == 2 else (0, 0)
-        rec = be.local_step(phase, P, n_input, level_lens, c0, c1, g, glo, ghi)
-        dist.all_gather_into_tensor(all_rec, rec, group=lp.group)           # the ONE exchange of the step
-        out = be.apply(all_rec, R, phase)
-        steps += 1
-        max_hit, n_accept, g, P = out[0], out[1], out[3], out[4]
+        glo, ghi = guess_shard(self.g, R, r) if phase == 2 else (0, 0)
+        rec = self.be.local_step(phase, self.P, self.n_input, level_lens, c0, c1, self.g, glo, ghi)
+        self.all_gather(self.all_rec, rec)                                       # the ONE exchange of the step
+        out = self.be.apply(self.all_rec, R, phase)
+        self.steps += 1
+        max_hit, n_accept, self.g, self.P = out[0], out[1], out[3], out[4]
         accepted = out[8:8 + n_accept]
         # EOS scan (lade/decoding.py:1167-1177): the reference keeps everything up to and including EOS
-        finished = False
-        if eos >= 0 and eos in accepted:
-            accepted = accepted[:accepted.index(eos) + 1]
-            finished = True
-        tokens += accepted
-        n_input = 1 + max_hit                                               # re-feed the hits (:1148-1153)
+        if self.eos >= 0 and self.eos in accepted:
+            accepted = accepted[:accepted.index(self.eos) + 1]
+            self.finished = True
+        self.tokens += accepted
+        self.n_input = 1 + max_hit                                           # re-feed the hits (:1148-1153)
         if phase != 2:
-            fill_level += 1
+            self.fill_level += 1
+        return dict(phase=phase, max_hit=max_hit, accepted=list(accepted), c0=c0, c1=c1, glo=glo, ghi=ghi, P_after=self.P, g_next=self.g,
+                    T=None)
+
+
+def greedy_lp(dec, prompt: Sequence[int], max_length: int, eos_token_id: Optional[int] = None,
+              rng: Optional[random.Random] = None, keep_trace: bool = False, backend=None, all_gather=None):
+    """Greedy lookahead decoding under lookahead parallelism (jacobi_greedy_search_multilevel with
+    DIST_WORKERS > 1, lade/decoding.py:697-1259)."""
+    from .decoding import GenOut
+    run = LPRunner(dec, backend, all_gather)
+    run.start(prompt, eos_token_id, rng)
+    trace: List[dict] = []
+    while True:
+        info = run.step()
         if keep_trace:
-            trace.append(dict(phase=phase, max_hit=max_hit, accepted=list(accepted), c0=c0, c1=c1, glo=glo, ghi=ghi, P_after=P, g_next=g))
-        if finished or len(tokens) >= max_length:
+            trace.append(info)
+        if run.finished or len(run.tokens) >= max_length:
             break
-    generated = min(len(tokens), max_length) - len(prompt)
-    return GenOut(tokens=tokens[:max_length], steps=steps, generated=generated, trace=trace)
+    generated = min(len(run.tokens), max_length) - len(run.prompt)
+    return GenOut(tokens=run.tokens[:max_length], steps=run.steps, generated=generated, trace=trace)

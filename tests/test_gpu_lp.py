@@ -78,26 +78,8 @@ def _run_rank(rank, R, run, ex, results, errors):
 
 
 def _greedy_lp_patched(parallel, dec, run, be, ex, rank):
-    # thread-local replacement of the collective used inside greedy_lp
-    real = parallel.dist.all_gather_into_tensor
-    tl = threading.local()
-
-    def ag(out, inp, group=None):
-        ex.all_gather(rank, out, inp)
-
-    class D:
-        all_gather_into_tensor = staticmethod(ag)
-        broadcast = staticmethod(lambda *a, **k: None)
-
-    # greedy_lp looks `dist` up in its module globals: give this thread its own view via a wrapper module object
-    import types
-    mod = types.ModuleType("parallel_thread")
-    mod.__dict__.update(parallel.__dict__)
-    mod.dist = D
-    code = parallel.greedy_lp.__code__
-    fn = types.FunctionType(code, mod.__dict__, "greedy_lp", parallel.greedy_lp.__defaults__)
-    fn.__kwdefaults__ = parallel.greedy_lp.__kwdefaults__
-    return fn(dec, run["prompt"], run["max_length"], rng=random.Random(run["seed"] + 1000 * rank), backend=be, keep_trace=True)
+    return parallel.greedy_lp(dec, run["prompt"], run["max_length"], rng=random.Random(run["seed"] + 1000 * rank), backend=be, keep_trace=True,
+                              all_gather=lambda out, inp: ex.all_gather(rank, out, inp))
 
 
 @pytest.mark.parametrize("idx", [0, 1, 2, 3])

@@ -1,0 +1,71 @@
+"""Skinny GEMM microbench vs torch.matmul (hipBLASLt): python tools/gemm_bench.py"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from lookaheaddecoding_amd import ops
+
+
+NO_REDUCE = bool(int(os.environ.get('NO_REDUCE', '0')))
+
+
+def timeit(fn, reps=50):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+shapes = [("qkv", 12288, 4096), ("o", 4096, 4096), ("gate_up", 22016, 4096), ("down", 4096, 11008), ("lm_head", 32000, 4096)]
+for M in (60, 120):
+    for name, N, K in shapes:
+        a = torch.randn(M, K, device="cuda").bfloat16()
+        # a few distinct weight copies so the stream comes from HBM, not from the 256 MB Infinity Cache
+        ws = [torch.randn(N, K, device="cuda").bfloat16() * 0.02 for _ in range(max(1, int(600e6 / (N * K * 2))))]
+        out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        i = [0]
+
+        def ref():
+            i[0] = (i[0] + 1) % len(ws)
+            torch.matmul(a, ws[i[0]].t(), out=out)
+
+        t_ref = timeit(ref)
+        res = []
+        want = torch.matmul(a.float(), ws[0].float().t())
+        for mb, bn in ([(2, 32), (2, 64), (2, 128), (2, 256)] if M <= 64 else [(4, 32), (4, 64), (4, 128), (4, 192), (4, 256)]):
+            for S in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16):
+                part = torch.empty(S, M, N, dtype=torch.float32, device="cuda") if S > 1 else None
+
+                def mine():
+                    i[0] = (i[0] + 1) % len(ws)
+                    if NO_REDUCE and S > 1:
+                        from lookaheaddecoding_amd.cabi import call, ptr, dtype_code
+                        call('lade_gemm_skinny', ptr(a), a.stride(0), ptr(ws[i[0]]), ws[i[0]].stride(0), ptr(out), out.stride(0), ptr(part), M, N, K, S, bn, mb, dtype_code(a))
+                    else:
+                        ops.gemm_skinny(a, ws[i[0]], out=out, n_split=S, bn=bn, part=part, mb=mb)
+
+                try:
+                    got = ops.gemm_skinny(a, ws[0], n_split=S, bn=bn, mb=mb).float()
+                    err = (got - want).abs().max().item()
+                    t = timeit(mine)
+                    res.append((t, f"{mb}x{bn}", S, err))
+                except Exception as ex:
+                    res.append((float("inf"), f"{mb}x{bn}", S, 0.0))
+        res.sort(key=lambda x: x[0])
+        mb = N * K * 2 / 1e6
+        best = res[0]
+        print(f"M={M:3d} {name:8s} N={N:5d} K={K:5d}  W={mb:6.1f} MB  torch {t_ref:7.2f} us ({mb / t_ref:5.2f} TB/s) | best mine {best[0]:7.2f} us "
+              f"({mb / best[0]:5.2f} TB/s) bn={best[1]} S={best[2]} err={best[3]:.3g} | " + " ".join(f"[{b}/{s}:{t:.1f}]" for t, b, s, _ in res[1:6]), flush=True)
