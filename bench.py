@@ -265,7 +265,7 @@ def main():
                     "note": "one layer's launch pair (attention + split combine) timed with hipEvents on the launch stream (lade_time_attn, 200 reps) at the end-of-run shape"}
         hot = hot_regime()
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:            # the CPU baseline is timed at N=1 only
             cpu = cpu_baseline(args, cfg)
         out = {
             "metric": "tokens/s, greedy lookahead decoding (W=15,N=5,G=15)" if (W, N, G) == (15, 5, 15) else f"tokens/s, greedy lookahead decoding (W={W},N={N},G={G})",
