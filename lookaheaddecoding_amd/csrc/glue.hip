@@ -78,21 +78,22 @@ template <> __device__ __forceinline__ u32x4 repack<F32>(const float* f) {
 }
 // Sum of the n_parts fp32 split-K partials of a GEMM output (fixed order: deterministic), rounded once to the
 // storage type like a library GEMM's output would be.  part_stride = elements between consecutive partials.
-template <typename T, int N>
-__device__ __forceinline__ void load_parts(const float* parts, int n_parts, size_t part_stride, size_t idx, float* out) {
+template <typename T, int N, int R>
+__device__ __forceinline__ void load_parts_r(const float* parts, int n_parts, size_t part_stride, size_t idx, float* out) {
 #pragma unroll
     for (int e = 0; e < N; ++e) out[e] = 0.f;
-    // 4 partials per round so that all their loads are in flight together; summation order stays 0,1,2,...
-    for (int s0 = 0; s0 < n_parts; s0 += 4) {
-        float4 v[4][N / 4];
+    // R partials per round: all their loads are in flight together (these kernels are latency bound); the
+    // summation order stays 0,1,2,...
+    for (int s0 = 0; s0 < n_parts; s0 += R) {
+        float4 v[R][N / 4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < R; ++j) {
             const float* p = parts + (size_t)min(s0 + j, n_parts - 1) * part_stride + idx;
 #pragma unroll
             for (int e = 0; e < N / 4; ++e) v[j][e] = *reinterpret_cast<const float4*>(p + 4 * e);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < R; ++j)
             if (s0 + j < n_parts) {
 #pragma unroll
                 for (int e = 0; e < N / 4; ++e) {
@@ -104,25 +105,35 @@ __device__ __forceinline__ void load_parts(const float* parts, int n_parts, size
     for (int e = 0; e < N; ++e) { const typename St<T>::S sv = stf<T>(out[e]); out[e] = ldf<T>(&sv, 0); }
 }
 
+template <typename T, int N>
+__device__ __forceinline__ void load_parts(const float* parts, int n_parts, size_t part_stride, size_t idx, float* out) {
+    if (n_parts <= 4) load_parts_r<T, N, 4>(parts, n_parts, part_stride, idx, out);      // wave-uniform
+    else load_parts_r<T, N, 8>(parts, n_parts, part_stride, idx, out);
+}
+
 // value after one rounding to the storage type
 template <typename T> __device__ __forceinline__ float rnd_st(float f) { typename St<T>::S s = stf<T>(f); return ldf<T>(&s, 0); }
 
 // y = w * cast(x_f32 * rsqrt(mean(x^2)+eps));  ADD: x <- cast(x + r) first (residual), norm of the sum.
-// One block per row, the row lives in registers (<= CH 16-byte chunks per thread): one HBM pass.
-template <typename T, bool ADD, int CH>
-__global__ __launch_bounds__(256) void rmsnorm_kernel(typename St<T>::S* x, const typename St<T>::S* r, const typename St<T>::S* w,
-                                                      typename St<T>::S* y, int hidden, float eps, const float* parts, int n_parts,
-                                                      size_t part_stride) {
+// One block of BT threads per row, the row lives in registers (<= CH 16-byte chunks per thread): one HBM pass.
+// Latency bound (rows <= 240): every load of the row - x, the residual or all its split-K partials, the norm
+// weight - is issued before the first use.
+template <typename T, bool ADD, int CH, int BT>
+__global__ __launch_bounds__(BT) void rmsnorm_kernel(typename St<T>::S* x, const typename St<T>::S* r, const typename St<T>::S* w,
+                                                     typename St<T>::S* y, int hidden, float eps, const float* parts, int n_parts,
+                                                     size_t part_stride) {
     constexpr int N = Vec<T>::N;
-    __shared__ float sm[8];
+    __shared__ float sm[BT / 64];
     const size_t base = (size_t)blockIdx.x * hidden;
     const int nvec = hidden / N;
     float v[CH][N];
+    u32x4 wv[CH];
     float ss = 0.f;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-        const int i = threadIdx.x + c * 256;
+        const int i = threadIdx.x + c * BT;
         if (i < nvec) {
+            wv[c] = *reinterpret_cast<const u32x4*>(w + (size_t)i * N);
             unpack<T>(*reinterpret_cast<const u32x4*>(x + base + (size_t)i * N), v[c]);
             if (ADD) {
                 float rr[N];
@@ -140,10 +151,10 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(typename St<T>::S* x, cons
     const float inv = rsqrtf(var + eps);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-        const int i = threadIdx.x + c * 256;
+        const int i = threadIdx.x + c * BT;
         if (i < nvec) {
             float ww[N], o[N];
-            unpack<T>(*reinterpret_cast<const u32x4*>(w + (size_t)i * N), ww);
+            unpack<T>(wv[c], ww);
 #pragma unroll
             for (int e = 0; e < N; ++e) o[e] = ww[e] * rnd_st<T>(v[c][e] * inv);     // weight * hidden.to(dtype)
             *reinterpret_cast<u32x4*>(y + base + (size_t)i * N) = repack<T>(o);
@@ -221,11 +232,13 @@ static int launch_rmsnorm(void* x, const void* r, const void* weight, void* y, i
                           const float* parts = nullptr, int n_parts = 0, size_t part_stride = 0) {
     const int nvec_bytes = dtype == LADE_F32 ? 4 : 8;
     LADE_REQUIRE(hidden % nvec_bytes == 0, LADE_E_ARG, "lade_rmsnorm: hidden=%d must be a multiple of %d", hidden, nvec_bytes);
-    const int chunks = cdiv(hidden / nvec_bytes, 256);
-    LADE_REQUIRE(chunks <= 8, LADE_E_LIMIT, "lade_rmsnorm: hidden=%d too large for the register-resident row", hidden);
-#define RMS_LAUNCH(CH) DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((rmsnorm_kernel<TT, ADD, CH>), dim3(rows), dim3(256), 0, st, (St<TT>::S*)x, \
-                                      (const St<TT>::S*)r, (const St<TT>::S*)weight, (St<TT>::S*)y, hidden, eps, parts, n_parts, part_stride))
-    if (chunks <= 1) { RMS_LAUNCH(1); } else if (chunks <= 2) { RMS_LAUNCH(2); } else if (chunks <= 4) { RMS_LAUNCH(4); } else { RMS_LAUNCH(8); }
+    const int vecs = hidden / nvec_bytes;              // 16-byte chunks per row
+    LADE_REQUIRE(vecs <= 8 * 512, LADE_E_LIMIT, "lade_rmsnorm: hidden=%d too large for the register-resident row", hidden);
+#define RMS_LAUNCH(CH, BT) DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((rmsnorm_kernel<TT, ADD, CH, BT>), dim3(rows), dim3(BT), 0, st, (St<TT>::S*)x, \
+                                          (const St<TT>::S*)r, (const St<TT>::S*)weight, (St<TT>::S*)y, hidden, eps, parts, n_parts, part_stride))
+    // one 16-byte chunk per thread up to 512 threads (every load of the row in flight at once), then 2 / 4 / 8 chunks
+    if (vecs <= 256) { RMS_LAUNCH(1, 256); } else if (vecs <= 512) { RMS_LAUNCH(1, 512); } else if (vecs <= 1024) { RMS_LAUNCH(2, 512); }
+    else if (vecs <= 2048) { RMS_LAUNCH(4, 512); } else { RMS_LAUNCH(8, 512); }
 #undef RMS_LAUNCH
     return check_launch(ADD ? "lade_add_rmsnorm" : "lade_rmsnorm");
 }

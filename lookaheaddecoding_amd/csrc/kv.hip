@@ -5,6 +5,7 @@
 // torch.cat in every layer of every step; here the cache is preallocated ([Hkv][S_max][d] keys,
 // [Hkv][d][S_max] transposed values) and only the T new rows are written.
 #include "common.hpp"
+#include <algorithm>
 
 namespace lade {
 
@@ -26,9 +27,9 @@ __device__ __forceinline__ float rnd(float f) {
 }
 
 // One launch does both halves of the append.
-//   blocks [0, T)           : token t.  q rotated in place, rotated k -> K cache row P+t.  A thread owns
-//                             VEC consecutive pairs (i, i+d/2) of one head: 16-byte loads / stores.
-//   blocks [T, T + n_vblk)  : V transpose.  Block (kv head, 64-token slab, 32-wide d chunk) stages the
+//   blocks [0, T*bpt)       : token t (bpt blocks per token).  q rotated in place, rotated k -> K cache row P+t.
+//                             A thread owns VEC consecutive pairs (i, i+d/2) of one head: 16-byte loads / stores.
+//   then n_vblk blocks      : V transpose.  Block (kv head, 64-token slab, 32-wide d chunk) stages the
 //                             slab through LDS and writes V^T[d][P+t] with the token index fastest.
 template <typename T>
 __global__ __launch_bounds__(256) void rope_kv_append_kernel(typename Elem<T>::S* qkv, const int32_t* positions,
@@ -37,14 +38,15 @@ __global__ __launch_bounds__(256) void rope_kv_append_kernel(typename Elem<T>::S
                                                              typename Elem<T>::S* k_cache, typename Elem<T>::S* vt_cache,
                                                              int T_, int P, const int32_t* dyn_P, int H, int Hkv, int d,
                                                              int S_max, int max_pos, const float* parts, int n_parts,
-                                                             size_t part_stride, typename Elem<T>::S* q_out) {
+                                                             size_t part_stride, typename Elem<T>::S* q_out, int bpt) {
     typedef typename Elem<T>::S S;
     constexpr int VEC = 16 / sizeof(S);
     __shared__ S sm[64][32 + 2];
     if (dyn_P) P = *dyn_P;
     const int row_w = (H + 2 * Hkv) * d;
-    if ((int)blockIdx.x < T_) {
-        const int t = blockIdx.x;
+    const int tok_blocks = T_ * bpt;                       // bpt blocks share one token row
+    if ((int)blockIdx.x < tok_blocks) {
+        const int t = blockIdx.x / bpt, sub = blockIdx.x - t * bpt;
         int pos = positions[t];
         pos = pos < 0 ? 0 : (pos >= max_pos ? max_pos - 1 : pos);
         const S* c = cos_tab + (size_t)pos * d;
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(256) void rope_kv_append_kernel(typename Elem<T>::S
         S* row = qkv + (size_t)t * row_w;
         if (half % VEC == 0) {
             const int vph = half / VEC;                               // vectors per half head
-            for (int idx = threadIdx.x; idx < (H + Hkv) * vph; idx += blockDim.x) {
+            for (int idx = sub * blockDim.x + threadIdx.x; idx < (H + Hkv) * vph; idx += bpt * blockDim.x) {
                 const int h = idx / vph, i = (idx - h * vph) * VEC;
                 S* x = row + (size_t)h * d;
                 S x1[VEC], x2[VEC], c1[VEC], c2[VEC], s1[VEC], s2[VEC], o1[VEC], o2[VEC];
@@ -62,15 +64,27 @@ __global__ __launch_bounds__(256) void rope_kv_append_kernel(typename Elem<T>::S
                     float a[VEC], b[VEC];
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) { a[e] = 0.f; b[e] = 0.f; }
-                    for (int sp = 0; sp < n_parts; ++sp) {
-                        const float* pa = parts + sp * part_stride + e0;
+                    // rounds of 8 partials: every load of a round is in flight before the first add (order 0,1,2,..)
+                    for (int s0 = 0; s0 < n_parts; s0 += 8) {
+                        float4 va[8][VEC / 4], vb[8][VEC / 4];
 #pragma unroll
-                        for (int e = 0; e < VEC; e += 4) {
-                            const float4 va = *reinterpret_cast<const float4*>(pa + e);
-                            const float4 vb = *reinterpret_cast<const float4*>(pa + half + e);
-                            a[e] += va.x; a[e + 1] += va.y; a[e + 2] += va.z; a[e + 3] += va.w;
-                            b[e] += vb.x; b[e + 1] += vb.y; b[e + 2] += vb.z; b[e + 3] += vb.w;
+                        for (int j = 0; j < 8; ++j) {
+                            const float* pa = parts + (size_t)min(s0 + j, n_parts - 1) * part_stride + e0;
+#pragma unroll
+                            for (int e = 0; e < VEC / 4; ++e) {
+                                va[j][e] = *reinterpret_cast<const float4*>(pa + 4 * e);
+                                vb[j][e] = *reinterpret_cast<const float4*>(pa + half + 4 * e);
+                            }
                         }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (s0 + j < n_parts) {
+#pragma unroll
+                                for (int e = 0; e < VEC / 4; ++e) {
+                                    a[4 * e] += va[j][e].x; a[4 * e + 1] += va[j][e].y; a[4 * e + 2] += va[j][e].z; a[4 * e + 3] += va[j][e].w;
+                                    b[4 * e] += vb[j][e].x; b[4 * e + 1] += vb[j][e].y; b[4 * e + 2] += vb[j][e].z; b[4 * e + 3] += vb[j][e].w;
+                                }
+                            }
                     }
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) { x1[e] = Elem<T>::st(a[e]); x2[e] = Elem<T>::st(b[e]); }
@@ -94,7 +108,7 @@ __global__ __launch_bounds__(256) void rope_kv_append_kernel(typename Elem<T>::S
                 *reinterpret_cast<uint4*>(dst + i + half) = *reinterpret_cast<const uint4*>(o2);
             }
         } else {
-            for (int idx = threadIdx.x; idx < (H + Hkv) * half; idx += blockDim.x) {
+            for (int idx = sub * blockDim.x + threadIdx.x; idx < (H + Hkv) * half; idx += bpt * blockDim.x) {
                 const int h = idx / half, i = idx - h * half;
                 S* x = row + (size_t)h * d;
                 const float a1 = Elem<T>::ld(x[i]), a2 = Elem<T>::ld(x[i + half]);
@@ -109,7 +123,7 @@ __global__ __launch_bounds__(256) void rope_kv_append_kernel(typename Elem<T>::S
     }
     // ---- V transpose ----
     const int dch = (d + 31) / 32;
-    int b = blockIdx.x - T_;
+    int b = blockIdx.x - tok_blocks;
     const int dc = b % dch; b /= dch;
     const int kvh = b % Hkv;
     const int t0 = (b / Hkv) * 64;
@@ -120,10 +134,14 @@ __global__ __launch_bounds__(256) void rope_kv_append_kernel(typename Elem<T>::S
             const int tt = idx >> 3, d4 = (idx & 7) * 4;
             if (tt < nt) {
                 const size_t e0 = (size_t)(t0 + tt) * row_w + (size_t)(H + Hkv + kvh) * d + d0 + d4;
-                float4 a = *reinterpret_cast<const float4*>(parts + e0);
-                for (int sp = 1; sp < n_parts; ++sp) {
-                    const float4 b = *reinterpret_cast<const float4*>(parts + sp * part_stride + e0);
-                    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+                float4 a = float4{0.f, 0.f, 0.f, 0.f};
+                for (int s0 = 0; s0 < n_parts; s0 += 8) {
+                    float4 pv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pv[j] = *reinterpret_cast<const float4*>(parts + (size_t)min(s0 + j, n_parts - 1) * part_stride + e0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (s0 + j < n_parts) { a.x += pv[j].x; a.y += pv[j].y; a.z += pv[j].z; a.w += pv[j].w; }
                 }
                 sm[tt][d4] = Elem<T>::st(a.x); sm[tt][d4 + 1] = Elem<T>::st(a.y); sm[tt][d4 + 2] = Elem<T>::st(a.z); sm[tt][d4 + 3] = Elem<T>::st(a.w);
             }
@@ -174,8 +192,12 @@ static int launch_rope(void* qkv, const int32_t* positions, const void* cos_tab,
                        hipStream_t st, const float* parts = nullptr, int n_parts = 0, size_t part_stride = 0, void* q_out = nullptr) {
     typedef typename Elem<T>::S S;
     const int n_vblk = Hkv * cdiv(T_, 64) * cdiv(d, 32);
-    hipLaunchKernelGGL(rope_kv_append_kernel<T>, dim3(T_ + n_vblk), dim3(256), 0, st, (S*)qkv, positions, (const S*)cos_tab,
-                       (const S*)sin_tab, (S*)k_cache, (S*)vt_cache, T_, P, dyn_P, H, Hkv, d, S_max, max_pos, parts, n_parts, part_stride, (S*)q_out);
+    // one 16-byte pair item per thread: blocks per token = items / 256 (latency bound: more, smaller work-groups)
+    constexpr int VEC = 16 / sizeof(S);
+    const int items = (d / 2) % VEC == 0 ? (H + Hkv) * (d / 2 / VEC) : (H + Hkv) * (d / 2);
+    const int bpt = std::max(1, std::min(8, cdiv(items, 256)));
+    hipLaunchKernelGGL(rope_kv_append_kernel<T>, dim3(T_ * bpt + n_vblk), dim3(256), 0, st, (S*)qkv, positions, (const S*)cos_tab,
+                       (const S*)sin_tab, (S*)k_cache, (S*)vt_cache, T_, P, dyn_P, H, Hkv, d, S_max, max_pos, parts, n_parts, part_stride, (S*)q_out, bpt);
     return check_launch("lade_rope_kv_append");
 }
 

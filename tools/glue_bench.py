@@ -9,14 +9,20 @@ import torch
 from lookaheaddecoding_amd import ops
 
 
-def timeit(fn, reps=300):
-    for _ in range(5):
+def timeit(fn, reps=100):
+    """mean time of one launch inside a hipGraph of `reps` dependent launches (what a decode step pays)"""
+    for _ in range(3):
         fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        fn()
+    g.replay()
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
@@ -55,6 +61,8 @@ def main():
         print(f"  rope_kv_append_parts n={n} {timeit(lambda: ops.rope_kv_append_parts(part, n, qb, pos, cos, sin, kc, vc, T, 500, H=H, Hkv=H, d=d)):7.2f} us")
     nothing = torch.zeros(1, device=dev)
     print(f"  (torch tiny add_)       {timeit(lambda: nothing.add_(1)):7.2f} us")
+    idx = torch.arange(T, dtype=torch.int32, device=dev)
+    print(f"  gather_rows             {timeit(lambda: ops.gather_rows(x, idx, out=h, rows=T)):7.2f} us")
 
 
 if __name__ == "__main__":
