@@ -74,6 +74,124 @@ def get_engine(model, need_seq: int, need_T: int) -> StepEngine:
     return eng
 
 
+# ---- model-step boundary: jforward_multilevel on the HIP step engine ---------------------------
+
+class EngineCache:
+    """Stands in for the reference's `past_key_values` tuple: the K/V rows live preallocated inside the step engine
+    (K row-major, V transposed); this handle only knows how many rows are valid.  The reference's caller edits the
+    cache after a step (copy the accepted candidate rows down, then slice; lade/decoding.py:1148-1163) - the same two
+    operations are `move_rows` and `crop` here."""
+
+    def __init__(self, engine: StepEngine, length: int):
+        self.engine, self.length = engine, int(length)
+
+    def __len__(self) -> int:
+        return self.length
+
+    def get_seq_length(self, layer_idx: int = 0) -> int:
+        return self.length
+
+    def crop(self, length: int) -> "EngineCache":
+        assert 0 <= length <= self.length
+        self.length = int(length)
+        return self
+
+    def move_rows(self, src: int, dst: int, cnt: int) -> "EngineCache":
+        from . import ops
+        if cnt > 0 and src != dst:
+            ops.kv_commit(self.engine.kv, src, dst, cnt)
+        return self
+
+
+class StepOutput:
+    """What the reference's loop reads from `jforward_multilevel`'s return value (lade/decoding.py:1012-1102):
+    out_logits [1,V], inp_logits [1,window,V], guess_logits [1,lguess,V] (fp32), past_key_values, kvcache_len, step_len.
+    `logits` is None: lm_head runs only on the rows above (the reference runs it on all T rows, modeling_llama.py:1541)."""
+
+    def __init__(self):
+        self.logits = None
+        self.out_logits = self.inp_logits = self.guess_logits = None
+        self.past_key_values = None
+        self.kvcache_len = self.step_len = 0
+        self.loss = self.hidden_states = self.attentions = None
+
+
+def jforward_multilevel(self, input_ids=None, past_tokens=None, guess_tokens=None, guess_size=2, not_seq=False, continue_all=False, level=3,
+                        fill_level=-1, WINDOWS_SIZE=-1, dist_workers=-1, local_rank=-1, la_mask_offset=0, use_flash=False, attention_mask=None,
+                        position_ids=None, past_key_values=None, inputs_embeds=None, labels=None, use_cache=None, output_attentions=None,
+                        output_hidden_states=None, return_dict=None) -> StepOutput:
+    """One lookahead model step with the reference's signature (lade/models/modeling_llama.py:1381-1608) on the HIP
+    step engine: assembles [inputs | L0 | L1.. | candidates] and their positions (:1487-1511), runs the fused step
+    under the closed-form mask, and returns the three logit slices the decode loop reads.  `past_tokens` may already be
+    a lookahead-parallel shard (lade/decoding.py:973-986): level sizes and the mask offsets follow from the list
+    lengths exactly as in the reference.  `past_key_values`: None (start a sequence) or the EngineCache a previous
+    call returned.  use_flash / not_seq / la_mask_offset are accepted for signature compatibility; there is one
+    attention path."""
+    from .ops import StepMask
+    assert labels is None, " Inference Mode "
+    assert input_ids.size(0) == 1, " single batch only "
+    assert continue_all is False or continue_all == 0
+    assert fill_level != -1
+    if level is not None:
+        assert level == len(past_tokens) + 1
+        assert guess_size == level - 1
+    gs = guess_size
+    n_input = input_ids.size(1)
+    in_ids = [int(t) for t in input_ids[0].tolist()]
+    in_pos = [int(t) for t in position_ids[0].tolist()]
+    lst_id = in_pos[-1]
+    past_size = 0 if past_key_values is None else len(past_key_values)
+    level_sizes, lv_ids, lv_pos = [], [], []
+    for ll in range(fill_level + 1):
+        toks = [int(t) for t in past_tokens[ll]]
+        level_sizes.append(len(toks))
+        lv_ids += toks
+        if ll == 0:
+            lv_pos += list(range(lst_id + 1, lst_id + 1 + len(toks)))
+        else:
+            off = len(past_tokens[0]) + 1 - len(toks)
+            lv_pos += list(range(lst_id + ll + off, lst_id + ll + off + len(toks)))
+    g_ids = [int(t) for t in guess_tokens] if guess_tokens is not None else []
+    lguess = len(g_ids)
+    g_pos = list(range(lst_id + 1, lst_id + 1 + gs)) * (lguess // gs) if lguess else []
+    ids, pos = in_ids + lv_ids + g_ids, in_pos + lv_pos + g_pos
+    T = len(ids)
+    is_prefill = past_tokens[1] is None
+    window = level_sizes[fill_level]
+    eng = get_engine(self, past_size + T + 64, min(T, 512))
+    if past_key_values is None:
+        eng.reset()
+    elif past_key_values.engine is not eng:
+        raise cabi.LadeHipError("past_key_values belongs to another step engine (the engine was rebuilt to grow its KV capacity)")
+    dev = eng.device
+    rows = [n_input - 1] + list(range(T - lguess - window, T - lguess)) + list(range(T - lguess, T))
+    done = 0
+    if is_prefill and T > eng.max_T:                  # long prompt: cache-filling chunks first (plain causal rows)
+        last_len = max(T - (n_input - 1), eng.max_T)  # the last chunk holds every row whose logits are read
+        while T - done > last_len:
+            n = min(eng.max_T, T - last_len - done)
+            eng.forward(torch.tensor(ids[done:done + n], dtype=torch.int32, device=dev), torch.tensor(pos[done:done + n], dtype=torch.int32, device=dev),
+                        StepMask(T=n, P=past_size + done, is_prefill=True), torch.zeros(1, dtype=torch.int32, device=dev), 0)
+            done += n
+    Tc = T - done
+    if Tc > eng.max_T:
+        raise cabi.LadeHipError(f"step of {Tc} tokens exceeds the engine's max_T={eng.max_T}")
+    mask = (StepMask(T=Tc, P=past_size + done, is_prefill=True) if is_prefill
+            else StepMask.from_levels(n_input, level_sizes, lguess, gs, past_size))
+    sel = torch.tensor([r - done for r in rows], dtype=torch.int32, device=dev)
+    logits = eng.forward(torch.tensor(ids[done:], dtype=torch.int32, device=dev), torch.tensor(pos[done:], dtype=torch.int32, device=dev),
+                         mask, sel, len(rows)).float()
+    ret = StepOutput()
+    ret.out_logits = logits[0:1]
+    ret.inp_logits = logits[1:1 + window].unsqueeze(0)
+    if lguess:
+        ret.guess_logits = logits[1 + window:].unsqueeze(0)
+    ret.past_key_values = EngineCache(eng, past_size + T)
+    ret.kvcache_len = n_input + past_size
+    ret.step_len = (attention_mask.size(1) if attention_mask is not None else past_size + n_input) + sum(level_sizes) + lguess
+    return ret
+
+
 def _criteria_limits(stopping_criteria, generation_config=None):
     max_length, eos = None, None
     for c in (stopping_criteria or []):

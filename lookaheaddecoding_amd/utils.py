@@ -49,10 +49,13 @@ def config_lade(WINDOW_SIZE=None, LEVEL=None, DEBUG=None, GUESS_SET_SIZE=None, A
 
 def augment_llama():
     """The reference copies its modified Llama methods over HF's classes (lade/utils.py:57-58).  Here the model step
-    is the HIP step engine, attached lazily to each LlamaForCausalLM at its first lookahead generate(); this call
-    only validates that the HIP extension is present, so a broken install fails at augment time."""
-    from . import cabi
+    is the HIP step engine, attached lazily to each LlamaForCausalLM at its first step; `jforward_multilevel` (the
+    model-step boundary the decode loop calls, lade/models/modeling_llama.py:1381) is installed on HF's class with the
+    reference's signature.  Loading the HIP extension here makes a broken install fail at augment time."""
+    from . import cabi, hf
     cabi.load_library()
+    from transformers.models.llama import modeling_llama
+    modeling_llama.LlamaForCausalLM.jforward_multilevel = hf.jforward_multilevel
 
 
 def augment_generate():

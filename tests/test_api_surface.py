@@ -72,3 +72,16 @@ def test_use_lade_without_gpu_fails_loudly(monkeypatch):
     with pytest.raises(cabi.LadeHipError):
         hf.jacobi_greedy_search_multilevel(model, torch.tensor([[1, 2, 3]]), max_length=8)
     lade.decoding.CONFIG_MAP.clear()
+
+
+def test_jforward_multilevel_has_the_reference_signature():
+    """The model-step boundary keeps the reference's parameter names and order (lade/models/modeling_llama.py:1381-1405)."""
+    import inspect
+    from lookaheaddecoding_amd import hf
+    names = list(inspect.signature(hf.jforward_multilevel).parameters)
+    assert names == ["self", "input_ids", "past_tokens", "guess_tokens", "guess_size", "not_seq", "continue_all", "level", "fill_level", "WINDOWS_SIZE",
+                     "dist_workers", "local_rank", "la_mask_offset", "use_flash", "attention_mask", "position_ids", "past_key_values", "inputs_embeds",
+                     "labels", "use_cache", "output_attentions", "output_hidden_states", "return_dict"]
+    out = hf.StepOutput()
+    for field in ("out_logits", "inp_logits", "guess_logits", "past_key_values", "kvcache_len", "step_len"):
+        assert hasattr(out, field)

@@ -49,3 +49,69 @@ def test_generate_with_use_lade_equals_plain_hf_greedy(hf_model, monkeypatch):
         GenerationMixin._sample = orig
         lade.decoding.FUNC_MAP.pop("_sample", None)
         lade.decoding.CONFIG_MAP.clear()
+
+
+def test_jforward_multilevel_boundary_matches_oracle_step(hf_model):
+    """The model-step boundary with the reference's signature (lade/models/modeling_llama.py:1381): prefill call,
+    a steady-state call with candidates, a lookahead-parallel shard, then the caller-side cache edit - logits against
+    the oracle's dense-mask model step on the same weights."""
+    import lade
+    from oracle import lade_oracle as O
+    from lookaheaddecoding_amd import hf
+    lade.augment_llama()
+    assert type(hf_model).jforward_multilevel is hf.jforward_multilevel
+    cfg = hf.config_from_hf(hf_model)
+    om = O.OracleLlama(cfg, {k: v.detach().float().cpu() for k, v in hf.weights_from_hf(hf_model).items()})
+    W, N = 5, 4
+    gs = N - 1
+    rng = random.Random(7)
+    prompt = [rng.randrange(3, 250) for _ in range(23)]
+    L0 = [rng.randrange(3, 250) for _ in range(W + N - 3)]
+    dev = "cuda"
+
+    def call(ids, pos, past_tokens, guess, fill_level, pkv):
+        return hf_model.jforward_multilevel(input_ids=torch.tensor([ids], device=dev), position_ids=torch.tensor([pos], device=dev),
+                                            attention_mask=torch.ones(1, (len(pkv) if pkv is not None else 0) + len(ids), dtype=torch.long, device=dev),
+                                            past_key_values=pkv, past_tokens=past_tokens, guess_tokens=guess, return_dict=True, level=N,
+                                            WINDOWS_SIZE=W, guess_size=gs, fill_level=fill_level, dist_workers=1, local_rank=0, use_flash=False)
+
+    def check(out, ref, tag):
+        assert out.logits is None and out.kvcache_len == ref.kvcache_len, tag
+        assert torch.allclose(out.out_logits[0].cpu(), ref.out_logits, atol=2e-4, rtol=1e-4), tag
+        assert torch.allclose(out.inp_logits[0].cpu(), ref.inp_logits, atol=2e-4, rtol=1e-4), tag
+        if ref.guess_logits is not None:
+            assert torch.allclose(out.guess_logits[0].cpu(), ref.guess_logits, atol=2e-4, rtol=1e-4), tag
+        else:
+            assert out.guess_logits is None, tag
+
+    # 1. prefill: prompt + level 0 (past_tokens[1] is None -> plain causal)
+    cache = om.new_cache()
+    pt = [list(L0)] + [None] * (N - 2)
+    ref = O.model_step(om, cache, prompt, list(range(len(prompt))), pt, None, 0, gs)
+    out = call(prompt, list(range(len(prompt))), pt, None, 0, None)
+    check(out, ref, "prefill")
+    assert len(out.past_key_values) == len(prompt) + len(L0) and out.step_len == len(prompt) + len(L0)
+    # the caller keeps only the prompt rows (lade/decoding.py:1130-1137 crops to kvcache_len)
+    pkv = out.past_key_values.crop(out.kvcache_len)
+    O.kv_truncate(cache, ref.kvcache_len)
+    # 2. steady state: full window + 2 candidates, one input token
+    lv = [[rng.randrange(3, 250) for _ in range(W - 1)]] + [[rng.randrange(3, 250) for _ in range(W)] for _ in range(N - 2)]
+    guess = [rng.randrange(3, 250) for _ in range(2 * gs)]
+    nxt, P = 77, len(prompt)
+    ref = O.model_step(om, cache, [nxt], [P], lv, guess, N - 2, gs)
+    out = call([nxt], [P], lv, guess, N - 2, pkv)
+    check(out, ref, "steady")
+    assert out.step_len == P + 1 + sum(len(x) for x in lv) + len(guess)
+    # caller-side edit: accept candidate 1 with 2 hits -> its rows move down, then crop
+    max_hit, idx = 2, 1
+    src = out.step_len - len(guess) + idx * gs
+    pkv = out.past_key_values.move_rows(src, out.kvcache_len, max_hit).crop(out.kvcache_len + max_hit)
+    O.kv_commit(cache, ref.kvcache_len, ref.step_len, len(guess), max_hit, idx, gs)
+    # 3. a lookahead-parallel shard (rank 1 of 2: columns 3..5) with re-fed hits as inputs (3 input tokens)
+    c0, c1 = 3, 5
+    sh = [lv[0][:c1 - 1]] + [l[c0:c1] for l in lv[1:]]
+    ins = [rng.randrange(3, 250) for _ in range(3)]
+    pos = [P + 3 + i for i in range(3)]
+    ref = O.model_step(om, cache, ins, pos, sh, guess[:gs], N - 2, gs)
+    out = call(ins, pos, sh, guess[:gs], N - 2, pkv)
+    check(out, ref, "lp shard")
