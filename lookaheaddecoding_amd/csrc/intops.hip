@@ -446,9 +446,10 @@ __global__ __launch_bounds__(64) void lp_pack_kernel(const int32_t* am_out, cons
 __global__ __launch_bounds__(64) void lp_reduce_apply_kernel(const int32_t* all_rec, int R, int rec_words, int split, int32_t* ctl,
                                                              int32_t* window, int wcap, int32_t* pool_tok, int32_t* pool_cnt, int V,
                                                              int W, int N, int G, int phase, int32_t* guess_all, int32_t* scratch,
-                                                             int32_t* record) {
+                                                             int32_t* record, int pool_from_prompt, int32_t* tail, int eos) {
     __shared__ int32_t tup[LADE_MAX_LEVEL];
     __shared__ int32_t hits[LADE_MAX_LEVEL];
+    __shared__ int32_t ng[LADE_MAX_LEVEL + 1];
     const int gs = N - 1;
     const int lane = threadIdx.x;
     const int P = ctl[LADE_CTL_P];
@@ -483,6 +484,9 @@ __global__ __launch_bounds__(64) void lp_reduce_apply_kernel(const int32_t* all_
     } else {
         window_fill(window, wcap, ctl, fill_level, scratch, total);
     }
+    // EOS scan + POOL_FROM_PROMPT appends, identical on every rank (lade/decoding.py:1167-1177)
+    int finished;
+    const int n_accept = accept_scan(hits, max_hit, eos, pool_from_prompt, tail, ng, pool_tok, pool_cnt, V, G, N, 0, &finished);
     const bool window_full = phase == 2 || ctl[LADE_CTL_FILL_LEVEL] >= N - 2;
     int g_next = 0;
     if (window_full) g_next = pool_lookup(pool_tok, pool_cnt, V, G, gs, new_lst, guess_all);
@@ -490,7 +494,7 @@ __global__ __launch_bounds__(64) void lp_reduce_apply_kernel(const int32_t* all_
     if (lane == 0) {
         ctl[LADE_CTL_MAX_HIT] = max_hit;
         ctl[LADE_CTL_MAX_HIT_IDX] = 0;
-        ctl[LADE_CTL_N_ACCEPT] = max_hit + 1;
+        ctl[LADE_CTL_N_ACCEPT] = n_accept;
         ctl[LADE_CTL_FIRST_GUESS] = first_guess;
         ctl[LADE_CTL_KV_CNT] = 0;
         ctl[LADE_CTL_P] = kvcache_len;                           // truncate; the hits are re-fed
@@ -500,8 +504,8 @@ __global__ __launch_bounds__(64) void lp_reduce_apply_kernel(const int32_t* all_
         ctl[LADE_CTL_G] = g_next;
         ctl[LADE_CTL_STEP] += 1;
         record[0] = max_hit;
-        record[1] = max_hit + 1;
-        record[2] = 0;
+        record[1] = n_accept;
+        record[2] = finished;
         record[3] = g_next;
         record[4] = kvcache_len;
         record[5] = win;
@@ -633,12 +637,14 @@ extern "C" int lade_lp_pack(const int32_t* am_out, const int32_t* am_inp, int32_
 
 extern "C" int lade_lp_reduce_apply(const int32_t* all_rec, int32_t R, int32_t rec_words, int32_t split, int32_t* ctl, int32_t* window,
                                     int32_t wcap, int32_t* pool_tok, int32_t* pool_cnt, int32_t V, int32_t W, int32_t N, int32_t G,
-                                    int32_t phase, int32_t* guess_all, int32_t* scratch, int32_t* record, void* stream) {
+                                    int32_t phase, int32_t* guess_all, int32_t* scratch, int32_t* record, int32_t pool_from_prompt,
+                                    int32_t* tail, int32_t eos, void* stream) {
     const int gs = N - 1;
     POOL_ARGS_OK("lade_lp_reduce_apply");
+    LADE_REQUIRE(!pool_from_prompt || tail, LADE_E_ARG, "lade_lp_reduce_apply: POOL_FROM_PROMPT needs the tail buffer");
     LADE_REQUIRE(all_rec && ctl && window && guess_all && scratch && record && R > 0 && rec_words >= 4 + gs + split && W <= wcap && N >= 3 && N <= LADE_MAX_LEVEL,
                  LADE_E_ARG, "lade_lp_reduce_apply: R=%d rec_words=%d split=%d", R, rec_words, split);
     hipLaunchKernelGGL(lp_reduce_apply_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, all_rec, R, rec_words, split, ctl, window, wcap,
-                       pool_tok, pool_cnt, V, W, N, G, phase, guess_all, scratch, record);
+                       pool_tok, pool_cnt, V, W, N, G, phase, guess_all, scratch, record, pool_from_prompt, tail, eos);
     return check_launch("lade_lp_reduce_apply");
 }

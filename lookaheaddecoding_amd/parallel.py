@@ -85,6 +85,10 @@ class HipLPBackend:
         d.st.reset(window0, len(prompt), prompt)
         self.prompt = list(prompt)
         self.window0 = list(window0)
+        self.eos = eos
+        if d.pool_from_prompt:                                   # lade/decoding.py:915-916, on every rank
+            pt = torch.tensor(self.prompt, dtype=torch.int32, device=self.device)
+            self.call("lade_pool_fill_prompt", self.ptr(d.st.pool_tok), self.ptr(d.st.pool_cnt), d.st.V, d.G, d.gs, self.ptr(pt), len(self.prompt))
 
     def local_step(self, phase: int, P: int, n_input: int, level_lens: Sequence[int], c0: int, c1: int, g: int, glo: int, ghi: int):
         """Builds this rank's inputs, runs the forward, and packs its record (device tensor [rw])."""
@@ -134,7 +138,7 @@ class HipLPBackend:
         d, st = self.dec, self.dec.st
         call, ptr = self.call, self.ptr
         call("lade_lp_reduce_apply", ptr(all_rec), R, self.rw, st.wcap, ptr(st.ctl), ptr(st.window), st.wcap, ptr(st.pool_tok), ptr(st.pool_cnt),
-             st.V, d.W, d.N, d.G, phase, ptr(st.guess), ptr(self.scratch), ptr(st.record))
+             st.V, d.W, d.N, d.G, phase, ptr(st.guess), ptr(self.scratch), ptr(st.record), int(d.pool_from_prompt), ptr(st.tail), self.eos)
         return st.read_record()
 
     def new_gather_buffer(self, R: int) -> torch.Tensor:
@@ -158,8 +162,6 @@ class LPRunner:
         self.W, self.N, self.G = dec.W, dec.N, dec.G
         if self.lp.R > self.W:
             raise ValueError(f"lookahead parallelism needs DIST_WORKERS ({self.lp.R}) <= WINDOW_SIZE ({self.W})")
-        if getattr(dec, "pool_from_prompt", False):
-            raise NotImplementedError("POOL_FROM_PROMPT is not supported under lookahead parallelism yet")
         self.be = backend if backend is not None else HipLPBackend(dec)
 
     def start(self, prompt: Sequence[int], eos_token_id: Optional[int] = None, rng: Optional[random.Random] = None) -> None:

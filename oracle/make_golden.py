@@ -373,7 +373,7 @@ def gen_e2e_sample():
 # ------------------------------------------------------------------ lookahead parallel (gloo)
 
 
-def _lp_worker(rank, R, port, mname, prompt, W, N, G, max_length, seed, q):
+def _lp_worker(rank, R, port, mname, prompt, W, N, G, max_length, seed, q, pfp=0):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -381,7 +381,7 @@ def _lp_worker(rank, R, port, mname, prompt, W, N, G, max_length, seed, q):
     torch.set_num_threads(1)
     cfg, w, model = get_model(mname)
     D.CONFIG_MAP.clear()
-    D.CONFIG_MAP.update(dict(WINDOW_SIZE=W, LEVEL=N, GUESS_SET_SIZE=G, ALWAYS_FWD_ONE=1, DEBUG=1, POOL_FROM_PROMPT=0, USE_FLASH=0, log=[],
+    D.CONFIG_MAP.update(dict(WINDOW_SIZE=W, LEVEL=N, GUESS_SET_SIZE=G, ALWAYS_FWD_ONE=1, DEBUG=1, POOL_FROM_PROMPT=pfp, USE_FLASH=0, log=[],
                              DIST_WORKERS=R, LOCAL_RANK=rank))
     rec = Recorder(model)
     random.seed(seed + rank * 1000)      # ranks differ: the reference broadcasts rank 0's window (:906)
@@ -401,14 +401,15 @@ def gen_e2e_lp():
     import torch.multiprocessing as mp
     runs = []
     port = 29611
-    for (mname, pname, W, N, G, new, seed, R) in [("tiny-d16", "rep", 5, 4, 5, 48, 1, 2), ("tiny-d16", "rep", 5, 4, 5, 48, 1, 3),
-                                                  ("tiny-d64", "rep2", 7, 5, 7, 40, 1, 2), ("tiny-d64", "rep", 5, 3, 3, 40, 2, 4)]:
+    for (mname, pname, W, N, G, new, seed, R, pfp) in [("tiny-d16", "rep", 5, 4, 5, 48, 1, 2, 0), ("tiny-d16", "rep", 5, 4, 5, 48, 1, 3, 0),
+                                                       ("tiny-d64", "rep2", 7, 5, 7, 40, 1, 2, 0), ("tiny-d64", "rep", 5, 3, 3, 40, 2, 4, 0),
+                                                       ("tiny-d16", "rep", 5, 4, 5, 48, 3, 2, 1), ("tiny-d64", "rep2", 6, 4, 4, 40, 2, 3, 1)]:
         cfg = make_config(mname)
         prompt = [t % cfg["vocab"] for t in PROMPTS[pname]]
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
         port += 1
-        procs = [ctx.Process(target=_lp_worker, args=(r, R, port, mname, prompt, W, N, G, len(prompt) + new, seed, q)) for r in range(R)]
+        procs = [ctx.Process(target=_lp_worker, args=(r, R, port, mname, prompt, W, N, G, len(prompt) + new, seed, q, pfp)) for r in range(R)]
         for p in procs:
             p.start()
         res = sorted([q.get(timeout=600) for _ in range(R)])
@@ -416,9 +417,9 @@ def gen_e2e_lp():
             p.join()
         assert all(r[1] == res[0][1] for r in res)
         runs.append({"model": mname, "model_seed": MODELS[mname]["seed"], "std": MODELS[mname]["std"], "prompt": prompt, "W": W, "N": N, "G": G,
-                     "max_length": len(prompt) + new, "seed": seed, "R": R, "tokens": res[0][1], "steps": res[0][2],
+                     "max_length": len(prompt) + new, "seed": seed, "R": R, "pool_from_prompt": pfp, "tokens": res[0][1], "steps": res[0][2],
                      "rank_traces": [r[3] for r in res]})
-        print("LP", mname, "R", R, "steps", res[0][2])
+        print("LP", mname, "R", R, "pool_from_prompt", pfp, "steps", res[0][2])
     dump("e2e_lp.json", {"runs": runs})
 
 

@@ -9,8 +9,9 @@ from lookaheaddecoding_amd.parallel import REC_HEAD, rec_words
 
 
 class OracleLPBackend:
-    def __init__(self, model, W, N, G):
+    def __init__(self, model, W, N, G, pool_from_prompt=False):
         self.model, self.W, self.N, self.G, self.gs = model, W, N, G, N - 1
+        self.pool_from_prompt = bool(pool_from_prompt)
         self.wcap = W + N - 3
         self.rw = rec_words(self.gs, self.wcap)
 
@@ -19,7 +20,10 @@ class OracleLPBackend:
         self.tokens = list(prompt)
         self.attn_len = len(prompt)
         self.past = [list(window0)] + [None] * (self.N - 2)
+        self.old_tail = list(prompt)[-self.N:]
         self.token_map = {}
+        if self.pool_from_prompt:
+            O.fill_pool_with_prompt(self.tokens, self.token_map, self.N, self.G)
         self.lst_token = None
         self.guess_all = None
         self.fill_level = 0
@@ -73,6 +77,10 @@ class OracleLPBackend:
         self.lst_token = hits[max_hit]
         self.tokens += hits[:max_hit + 1]
         self.attn_len += max_hit + 1
+        if self.pool_from_prompt:                     # lade/decoding.py:1167-1177: hits[max_hit] once per accepted index
+            for _ in range(max_hit + 1):
+                self.old_tail = (self.old_tail + [hits[max_hit]])[-N:]
+                O.append_new_generated_pool(self.old_tail, self.token_map, N, G)
         self.guess_all = O.pool_lookup(self.token_map, self.lst_token, self.past[N - 2] is not None, G)
         g_next = len(self.guess_all) // gs if self.guess_all else 0
         return [max_hit, max_hit + 1, 0, g_next, self.kvcache_len, win, fg, len(toks)] + list(hits) + [0] * 8

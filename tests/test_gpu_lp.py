@@ -51,7 +51,8 @@ def _run_rank(rank, R, run, ex, results, errors):
         cfg = make_config(run["model"], max_pos=512)
         w = {k: torch.as_tensor(v) for k, v in random_weights_numpy(cfg, seed=run["model_seed"], std=run["std"]).items()}
         eng = StepEngine(cfg, w, dtype=torch.float32, max_seq=512, max_T=320)
-        dec = LookaheadDecoder(eng, run["W"], run["N"], run["G"], lp=parallel.LPContext(rank=rank, world=R))
+        dec = LookaheadDecoder(eng, run["W"], run["N"], run["G"], lp=parallel.LPContext(rank=rank, world=R),
+                               pool_from_prompt=bool(run.get("pool_from_prompt", 0)))
         be = parallel.HipLPBackend(dec)
         be.broadcast_window = lambda w0, lp: (lambda t: (ex.broadcast(rank, t), t.tolist())[1])(torch.tensor(w0, dtype=torch.int32, device="cuda"))
         ids_per_step = []
@@ -82,7 +83,7 @@ def _greedy_lp_patched(parallel, dec, run, be, ex, rank):
                               all_gather=lambda out, inp: ex.all_gather(rank, out, inp))
 
 
-@pytest.mark.parametrize("idx", [0, 1, 2, 3])
+@pytest.mark.parametrize("idx", [0, 1, 2, 3, 4, 5])
 def test_lp_hip_kernels_match_reference_gloo_runs(idx):
     with open(os.path.join(GOLDEN, "e2e_lp.json")) as f:
         run = json.load(f)["runs"][idx]

@@ -44,7 +44,8 @@ def _worker(rank, R, port, run, q):
     d = Dec()
     d.W, d.N, d.G, d.gs = run["W"], run["N"], run["G"], run["N"] - 1
     d.lp = LPContext(rank=rank, world=R)
-    be = OracleLPBackend(model, d.W, d.N, d.G)
+    d.pool_from_prompt = bool(run.get("pool_from_prompt", 0))
+    be = OracleLPBackend(model, d.W, d.N, d.G, pool_from_prompt=d.pool_from_prompt)
     ids_per_step = []
     orig = be.local_step
 
@@ -60,7 +61,7 @@ def _worker(rank, R, port, run, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("idx", [0, 1, 2, 3])
+@pytest.mark.parametrize("idx", [0, 1, 2, 3, 4, 5])
 def test_lp_orchestration_matches_reference_gloo_runs(idx):
     with open(os.path.join(GOLDEN, "e2e_lp.json")) as f:
         runs = json.load(f)["runs"]

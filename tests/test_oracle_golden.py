@@ -110,7 +110,7 @@ def test_lookahead_parallel_matches_reference_gloo_runs():
     for run in d["runs"]:
         model = oracle_model(run)
         res = O.lookahead_greedy(model, run["prompt"], run["W"], run["N"], run["G"], run["max_length"], random.Random(run["seed"]),
-                                 R=run["R"])
+                                 R=run["R"], pool_from_prompt=bool(run.get("pool_from_prompt", 0)))
         _check_trace(res, run, run["rank_traces"])
 
 
