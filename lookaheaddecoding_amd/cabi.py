@@ -114,7 +114,9 @@ def lib() -> C.CDLL:
 
 
 def stream_ptr() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """Raw hipStream_t of torch's current stream on the current device (the C-level getter: an eager step issues
+    several hundred entry-point calls, torch.cuda.current_stream() would cost more than the launches themselves)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def check(rc: int, what: str) -> None:

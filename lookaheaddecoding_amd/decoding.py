@@ -142,7 +142,9 @@ class LookaheadDecoder:
         G = self.G
         return sorted({0, (G + 3) // 4, (G + 1) // 2, G})
 
-    def _graph_body(self, gcap: int) -> None:
+    def _graph_body(self, gcap: int, forward_only: bool = False):
+        """forward_only (sampling): input assembly + model step + argmax; the fp32 logits of the selected rows stay in
+        the graph's memory pool for the host-side verify, the post-step is launched afterwards with the forced hits."""
         e, st = self.e, self.st
         W, N, G, gs = self.W, self.N, self.G, self.gs
         cand_rows = gcap * gs
@@ -152,15 +154,17 @@ class LookaheadDecoder:
              ptr(st.ids), ptr(st.pos), None)
         logits = e.forward(st.ids, st.pos, mask, self._graph_sel[gcap], 1 + W + cand_rows, dyn_P=st.ctl, n_splits=self._graph_splits[gcap])
         ops.argmax_rows(logits, out=st.am)
+        if forward_only:
+            return logits.float()                                   # logits.float(), modeling_llama.py:1544
         call("lade_greedy_post_step", ptr(st.ctl), ptr(st.window), st.wcap, ptr(st.pool_tok), ptr(st.pool_cnt), st.V, W, N, G,
              ptr(st.am), W, ptr(st.guess), T, cand_rows, 2, int(self.pool_from_prompt), ptr(st.tail), self.eos, None, None, ptr(st.record))
         ops.kv_commit(e.kv, 0, 0, 0, ctl=st.ctl)
         st.record_host.copy_(st.record, non_blocking=True)
 
-    def _capture_graphs(self) -> None:
+    def _capture_graphs(self, forward_only: bool = False) -> None:
         e, st = self.e, self.st
         W, N, gs = self.W, self.N, self.gs
-        self._graphs, self._graph_sel, self._graph_splits, self._graph_T = {}, {}, {}, {}
+        self._graphs, self._graph_sel, self._graph_splits, self._graph_T, self._graph_logits = {}, {}, {}, {}, {}
         state = (st.ctl, st.window, st.pool_cnt, st.pool_tok, st.guess, st.tail)
         saved = [t.clone() for t in state]
         for gcap in self._buckets():
@@ -175,21 +179,21 @@ class LookaheadDecoder:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                self._graph_body(gcap)
+                self._graph_body(gcap, forward_only)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             for t, sv in zip(state, saved):
                 t.copy_(sv)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._graph_body(gcap)
+                self._graph_logits[gcap] = self._graph_body(gcap, forward_only)
             self._graphs[gcap] = g
-        self._graph = True
+        self._graph = "forward" if forward_only else "step"
         self._graph_eos = self.eos
 
     def _step_graph(self) -> dict:
         e, st = self.e, self.st
-        if self._graph is None or self._graph_eos != self.eos:
+        if self._graph != "step" or self._graph_eos != self.eos:
             self._capture_graphs()
         gcap = min(b for b in self._graphs if b >= self.g)
         T = self._graph_T[gcap]
@@ -330,6 +334,18 @@ class LookaheadDecoder:
                 mask = StepMask(T=T, P=done, is_prefill=True)
                 n_inp, cand_rows = len(self.window0), 0
                 n_input = len(prompt_l) - done
+            elif self.use_graph and fill_level >= N - 2:
+                # steady step: input assembly + model step + argmax replayed as one hipGraph (candidate rows padded to the bucket)
+                if self._graph != "forward":
+                    self._capture_graphs(forward_only=True)
+                phase, n_input, n_inp = 2, 1, W
+                gcap = min(b for b in self._graphs if b >= g)
+                T, cand_rows = self._graph_T[gcap], gcap * gs
+                if P + T > e.S_max:
+                    raise cabi.LadeHipError(f"KV cache exhausted: P={P} + T={T} > S_max={e.S_max}")
+                mask = StepMask.from_levels(1, self._level_sizes(N - 2), cand_rows, gs, P)
+                self._graphs[gcap].replay()
+                logits = self._graph_logits[gcap]
             else:
                 phase = 2 if fill_level >= N - 2 else 1
                 n_input = 1
@@ -340,10 +356,11 @@ class LookaheadDecoder:
                 call("lade_build_inputs", None, None, n_input, ptr(st.window), st.wcap, ptr(st.ctl), min(fill_level, N - 2), 0, -1,
                      ptr(st.guess), g if phase == 2 else 0, gs, cand_rows, ptr(st.ids), ptr(st.pos), None)
                 n_inp = ls[-1]
-            rows = [n_input - 1] + list(range(T - cand_rows - n_inp, T - cand_rows)) + list(range(T - cand_rows, T))
-            n_sel = self._set_sel(rows)
-            logits = e.forward(st.ids, st.pos, mask, st.sel, n_sel).float()        # logits.float(), modeling_llama.py:1544
-            ops.argmax_rows(logits, out=st.am)                                        # window levels are filled by argmax (:459, :545)
+            if not (self.use_graph and self.steps > 0 and fill_level >= N - 2):
+                rows = [n_input - 1] + list(range(T - cand_rows - n_inp, T - cand_rows)) + list(range(T - cand_rows, T))
+                n_sel = self._set_sel(rows)
+                logits = e.forward(st.ids, st.pos, mask, st.sel, n_sel).float()    # logits.float(), modeling_llama.py:1544
+                ops.argmax_rows(logits, out=st.am)                                    # window levels are filled by argmax (:459, :545)
             next_scores = warp(logits[0:1])
             max_hit, max_hit_idx = 0, 0
             if phase == 2 and g > 0:

@@ -119,12 +119,13 @@ def test_sampling_fp32_identical_tokens_vs_reference():
     d = load("e2e_sample.json")
     for run in d["runs"]:
         cfg, w, eng = make_engine(run, torch.float32)
-        dec = LookaheadDecoder(eng, run["W"], run["N"], run["G"])
-        torch.manual_seed(run["seed"])
-        out = dec.sample(run["prompt"], run["max_length"], warp=make_warper(**run["warp"]), rng=random.Random(run["seed"]),
-                         torch_gen=torch.default_generator)
-        assert out.tokens == run["tokens"], run["warp"]
-        assert out.steps == run["steps"]
+        for use_graph in (False, True):             # True: steady steps replay the forward-only hipGraph
+            dec = LookaheadDecoder(eng, run["W"], run["N"], run["G"], use_graph=use_graph)
+            torch.manual_seed(run["seed"])
+            out = dec.sample(run["prompt"], run["max_length"], warp=make_warper(**run["warp"]), rng=random.Random(run["seed"]),
+                             torch_gen=torch.default_generator)
+            assert out.tokens == run["tokens"], (run["warp"], use_graph)
+            assert out.steps == run["steps"]
 
 
 def test_sampling_logits_within_tolerance_bf16():

@@ -30,7 +30,7 @@ def timeit(fn, reps=50):
 
 
 shapes = [("qkv", 12288, 4096), ("o", 4096, 4096), ("gate_up", 22016, 4096), ("down", 4096, 11008), ("lm_head", 32000, 4096)]
-for M in (60, 120):
+for M in [int(x) for x in os.environ.get('M', '60,120').split(',')]:
     for name, N, K in shapes:
         a = torch.randn(M, K, device="cuda").bfloat16()
         # a few distinct weight copies so the stream comes from HBM, not from the 256 MB Infinity Cache
@@ -45,7 +45,7 @@ for M in (60, 120):
         t_ref = timeit(ref)
         res = []
         want = torch.matmul(a.float(), ws[0].float().t())
-        for mb, bn in ([(2, 32), (2, 64), (2, 128), (2, 256)] if M <= 64 else [(4, 32), (4, 64), (4, 128), (4, 192), (4, 256)]):
+        for mb, bn in ([(2, 32), (2, 64), (2, 128), (2, 256)] if M <= 64 else [(4, 64), (4, 128), (4, 192), (4, 256), (2, 64), (2, 128), (2, 256)]):
             for S in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16):
                 part = torch.empty(S, M, N, dtype=torch.float32, device="cuda") if S > 1 else None
 
