@@ -19,6 +19,7 @@ namespace lade {
 // insert (possibly to the same key) observes this one.
 __device__ void lru_insert(int32_t* pool_tok, int32_t* pool_cnt, int V, int G, int gs, int key, const int32_t* tup) {
     const int lane = threadIdx.x;
+    if (G <= 0) return;      // GUESS_SET_SIZE <= 0: the reference never reads the pool (lade/decoding.py:948), nothing to keep
     if (key >= 0 && key < V) {
         const int cnt = pool_cnt[key];
         int32_t* slots = pool_tok + (size_t)key * G * gs;
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(64) void lp_reduce_apply_kernel(const int32_t* all_
 using namespace lade;
 
 #define POOL_ARGS_OK(fn) \
-    LADE_REQUIRE(pool_tok && pool_cnt && V > 0 && G > 0 && G <= LADE_MAX_GUESS_SET && gs > 0 && gs < LADE_MAX_LEVEL, LADE_E_ARG, \
+    LADE_REQUIRE(pool_tok && pool_cnt && V > 0 && G >= 0 && G <= LADE_MAX_GUESS_SET && gs > 0 && gs < LADE_MAX_LEVEL, LADE_E_ARG, \
                  fn ": V=%d G=%d gs=%d (limits: G<=%d, gs<%d)", V, G, gs, LADE_MAX_GUESS_SET, LADE_MAX_LEVEL)
 
 extern "C" int lade_pool_insert_window(int32_t* pool_tok, int32_t* pool_cnt, int32_t V, int32_t G, int32_t gs,

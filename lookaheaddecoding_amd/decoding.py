@@ -41,8 +41,8 @@ class LadeState:
     def __init__(self, V: int, W: int, N: int, G: int, device, max_T: int):
         if not (3 <= N <= cabi.MAX_LEVEL):
             raise cabi.LadeHipError(f"LEVEL={N} unsupported (3..{cabi.MAX_LEVEL}; the reference itself needs LEVEL >= 3)")
-        if not (1 <= G <= cabi.MAX_GUESS_SET):
-            raise cabi.LadeHipError(f"GUESS_SET_SIZE={G} unsupported (1..{cabi.MAX_GUESS_SET})")
+        if not (0 <= G <= cabi.MAX_GUESS_SET):
+            raise cabi.LadeHipError(f"GUESS_SET_SIZE={G} unsupported (0..{cabi.MAX_GUESS_SET}; <= 0 means no verification branch)")
         if W < 1 or W + N - 3 > cabi.MAX_WINDOW:
             raise cabi.LadeHipError(f"WINDOW_SIZE={W} unsupported")
         self.V, self.W, self.N, self.G, self.gs = V, W, N, G, N - 1
@@ -50,9 +50,9 @@ class LadeState:
         i32 = dict(dtype=torch.int32, device=device)
         self.window = torch.zeros(N - 1, self.wcap, **i32)
         self.ctl = torch.zeros(CTL_WORDS, **i32)
-        self.pool_tok = torch.zeros(V, G, self.gs, **i32)
+        self.pool_tok = torch.zeros(V, max(G, 1), self.gs, **i32)
         self.pool_cnt = torch.zeros(V, **i32)
-        self.guess = torch.zeros(G * self.gs, **i32)
+        self.guess = torch.zeros(max(G, 1) * self.gs, **i32)
         self.tail = torch.zeros(N + 2, **i32)
         self.ids = torch.zeros(max_T, **i32)
         self.pos = torch.zeros(max_T, **i32)
@@ -88,6 +88,10 @@ class LookaheadDecoder:
         self.e = engine
         self.use_graph = bool(use_graph)
         self._graph = None
+        # GUESS_SET_SIZE <= 0 (-1 = "unlimited" in the reference's README): both reference loops gate the verification
+        # branch on `GUESS_SET_SIZE > 0` (lade/decoding.py:402, :948), so the pool is filled but never read and every
+        # step accepts exactly one token.  Reproduced as G = 0: no pool, no candidates.
+        G = max(int(G), 0)
         self.W, self.N, self.G, self.gs = W, N, G, N - 1
         self.pool_from_prompt = bool(pool_from_prompt)
         self.lp = lp                      # lookahead-parallel context (parallel.LPContext) or None

@@ -329,6 +329,22 @@ def gen_e2e_greedy():
     np.savez_compressed(os.path.join(GOLD, "attn_steps.npz"), **attn_npz)
     print("wrote attn_steps.npz", os.path.getsize(os.path.join(GOLD, "attn_steps.npz")))
 
+
+
+def gen_e2e_unlimited():
+    """GUESS_SET_SIZE = -1 ("unlimited" pool): both reference loops gate the verification branch on GUESS_SET_SIZE > 0
+    (lade/decoding.py:402, :948), so the pool is only written - one token per step.  Small separate fixture."""
+    runs = []
+    for (mname, pname, W, N, new, seed, pfp) in [("tiny-d16", "rep", 5, 4, 32, 1, 0), ("tiny-d64", "rep2", 4, 3, 28, 2, 1)]:
+        cfg, w, model = get_model(mname)
+        prompt = [t % cfg["vocab"] for t in PROMPTS[pname]]
+        toks, steps, gen, rec = run_ref_greedy(model, prompt, W, N, -1, len(prompt) + new, seed, pfp, None)
+        runs.append({"model": mname, "model_seed": MODELS[mname]["seed"], "std": MODELS[mname]["std"], "prompt": prompt, "W": W, "N": N, "G": -1,
+                     "max_length": len(prompt) + new, "seed": seed, "pool_from_prompt": pfp, "eos": None, "tokens": toks, "steps": steps,
+                     "generated": gen, "trace": rec.steps})
+        print("unlimited", mname, "steps", steps, "gen", gen)
+    dump("e2e_unlimited.json", {"runs": runs})
+
 # ------------------------------------------------------------------ sampling
 
 
@@ -424,7 +440,7 @@ def gen_e2e_lp():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["pool", "mask", "greedy", "sample", "lp"]
+    what = sys.argv[1:] or ["pool", "mask", "greedy", "sample", "lp", "unlimited"]
     torch.set_num_threads(4)
     if "pool" in what:
         gen_pool()
@@ -436,3 +452,5 @@ if __name__ == "__main__":
         gen_e2e_sample()
     if "lp" in what:
         gen_e2e_lp()
+    if "unlimited" in what:
+        gen_e2e_unlimited()

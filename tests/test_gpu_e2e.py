@@ -51,6 +51,19 @@ def test_greedy_fp32_identical_tokens_steps_and_trace_vs_reference():
     assert n >= 10
 
 
+def test_unlimited_guess_set_matches_reference():
+    """GUESS_SET_SIZE = -1 ("unlimited"): the reference never enters the verification branch; eager and graph mode."""
+    from lookaheaddecoding_amd.decoding import LookaheadDecoder
+    for run in load("e2e_unlimited.json")["runs"]:
+        cfg, w, eng = make_engine(run, torch.float32)
+        for use_graph in (False, True):
+            dec = LookaheadDecoder(eng, run["W"], run["N"], run["G"], pool_from_prompt=bool(run["pool_from_prompt"]), use_graph=use_graph)
+            out = dec.greedy(run["prompt"], run["max_length"], rng=random.Random(run["seed"]), keep_trace=True)
+            assert out.tokens == run["tokens"] and out.steps == run["steps"] == out.generated
+            for i, (mine, ref) in enumerate(zip(out.trace, run["trace"])):
+                assert mine["T"] == len(ref["ids"]) and mine["P_before"] == ref["P"] and mine["first_guess"] == ref["out_argmax"], (i, use_graph)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_greedy_16bit_equals_plain_greedy_and_scores_within_tolerance(dtype):
     """Output-identity property of lookahead decoding (README.md:132) on the MFMA path, and every emitted

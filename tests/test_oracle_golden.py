@@ -105,6 +105,17 @@ def test_greedy_e2e_matches_reference_traces():
             assert res.tokens == run["plain"][:len(res.tokens)]
 
 
+def test_unlimited_guess_set_never_verifies_like_the_reference():
+    """GUESS_SET_SIZE = -1: the reference's loops gate verification on GUESS_SET_SIZE > 0 (lade/decoding.py:402, :948)."""
+    d = load("e2e_unlimited.json")
+    for run in d["runs"]:
+        model = oracle_model(run)
+        res = O.lookahead_greedy(model, run["prompt"], run["W"], run["N"], run["G"], run["max_length"], random.Random(run["seed"]),
+                                 eos_token_id=run["eos"], pool_from_prompt=bool(run["pool_from_prompt"]))
+        _check_trace(res, run)
+        assert res.steps == res.generated
+
+
 def test_lookahead_parallel_matches_reference_gloo_runs():
     d = load("e2e_lp.json")
     for run in d["runs"]:
