@@ -91,7 +91,10 @@ extern "C" {
 /* The lookahead mask in closed form (reference: j_make_causal_mask_multilevel,
  * lade/models/modeling_llama.py:115-207; its flash counterpart gets the same information as
  * lookahead=[window, level, n_guess, kv_cache, fill_offset, guess_offset, 0], :1184-1187).
- * Token order of the T new rows: [n_input inputs | L0 | L1 .. | g*gs candidate tokens]. */
+ * Token order of the T new rows: [n_input inputs | L0 | L1 .. | g*gs candidate tokens] (layout 0, the eager
+ * path's order), or with levels >= 1 interleaved column-major [.. | L0 | L1[0] L2[0] .. | L1[1] L2[1] .. | ..]
+ * (layout 1: the order the reference feeds its flash kernel, modeling_llama.py:1471-1485); q rows, the new
+ * K/V rows and the output rows all follow the chosen order. */
 typedef struct lade_mask_params {
     int32_t T;            /* new tokens this step (query rows; keys P..P+T) */
     int32_t P;            /* cached keys, visible to every row */
@@ -101,6 +104,7 @@ typedef struct lade_mask_params {
     int32_t gs;           /* tokens per candidate = N-1 */
     int32_t level_offset; /* n_input-1 = guess_offset */
     int32_t dist_offset;  /* 1 + level_sizes[0] - level_sizes[-1]  (fill_offset = level_offset+dist_offset) */
+    int32_t layout;       /* 0 = level-major rows (eager order), 1 = levels >= 1 column-major (flash order) */
 } lade_mask_params;
 
 typedef struct lade_attn_args {

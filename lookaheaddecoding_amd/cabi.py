@@ -34,7 +34,7 @@ class LadeHipError(RuntimeError):
 
 class MaskParams(C.Structure):
     _fields_ = [("T", C.c_int32), ("P", C.c_int32), ("is_prefill", C.c_int32), ("s", C.c_int32), ("lguess", C.c_int32),
-                ("gs", C.c_int32), ("level_offset", C.c_int32), ("dist_offset", C.c_int32)]
+                ("gs", C.c_int32), ("level_offset", C.c_int32), ("dist_offset", C.c_int32), ("layout", C.c_int32)]
 
 
 class AttnArgs(C.Structure):

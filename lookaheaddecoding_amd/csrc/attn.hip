@@ -71,6 +71,15 @@ __device__ __forceinline__ RowDesc make_row(int t, bool valid, const lade_mask_p
         return r;
     }
     r.kind = 1; r.a = A;
+    if (m.layout == 1 && t >= A + m.s) {
+        // flash order (modeling_llama.py:1471-1485): after block 0, the levels >= 1 are interleaved column-major
+        const int nl = (m.T - m.lguess - A - m.s) / m.s;      // levels >= 1
+        const int q = t - (A + m.s);
+        r.i = q / nl;
+        r.ll = 1 + (q - r.i * nl);
+        r.cbase = A + m.s + r.i * nl;                           // this column's keys of levels 1..: contiguous
+        return r;
+    }
     r.ll = (t - A) / m.s;
     r.i = (t - A) - r.ll * m.s;
     return r;
@@ -94,9 +103,13 @@ __device__ __forceinline__ uint64_t vis_bits(int c0, const RowDesc& r, const lad
         v = range_bits(c0, NEG, r.t);
     } else if (r.kind == 1) {
         v = range_bits(c0, NEG, r.a + r.i);                       // cols < A, block-0 prefix j <= i
-        for (int rr = 1; rr <= r.ll; ++rr) {                       // own column of blocks 1..ll
-            const int c = r.a + r.i + rr * m.s;
-            v |= range_bits(c0, c, c);
+        if (m.layout == 1) {
+            if (r.ll >= 1) v |= range_bits(c0, r.cbase, r.cbase + r.ll - 1);   // own column, levels 1..ll (adjacent keys)
+        } else {
+            for (int rr = 1; rr <= r.ll; ++rr) {                   // own column of blocks 1..ll
+                const int c = r.a + r.i + rr * m.s;
+                v |= range_bits(c0, c, c);
+            }
         }
     } else if (r.kind == 2) {
         v = range_bits(c0, NEG, m.level_offset) | range_bits(c0, r.cbase, r.cbase + r.pos);
@@ -595,6 +608,7 @@ static int validate(const lade_attn_args* a) {
                      m.level_offset, m.dist_offset);
         // s == 0: a lookahead-parallel rank that owns no window column feeds only the L0 prefix (all causal rows)
         const int body = m.T - m.lguess - (m.level_offset + m.dist_offset);
+        LADE_REQUIRE(m.layout == 0 || m.layout == 1, LADE_E_ARG, "lade_attn: mask layout=%d", m.layout);
         LADE_REQUIRE(body >= 0 && (m.s > 0 ? body % m.s == 0 : body == 0), LADE_E_ARG,
                      "lade_attn: T=%d is not offsets(%d)+k*s(%d)+lguess(%d)", m.T, m.level_offset + m.dist_offset, m.s, m.lguess);
     }

@@ -28,15 +28,16 @@ class StepMask:
     gs: int = 1
     level_offset: int = 0
     dist_offset: int = 0
+    layout: int = 0          # 0: rows level-major (eager order); 1: levels >= 1 column-major (the reference's flash order)
 
     @staticmethod
-    def from_levels(n_input: int, level_sizes, lguess: int, gs: int, P: int, is_prefill: bool = False) -> "StepMask":
+    def from_levels(n_input: int, level_sizes, lguess: int, gs: int, P: int, is_prefill: bool = False, layout: int = 0) -> "StepMask":
         T = n_input + sum(level_sizes) + lguess
         return StepMask(T=T, P=P, is_prefill=is_prefill, s=level_sizes[-1], lguess=lguess, gs=gs, level_offset=n_input - 1,
-                        dist_offset=1 + level_sizes[0] - level_sizes[-1])
+                        dist_offset=1 + level_sizes[0] - level_sizes[-1], layout=layout)
 
     def c_struct(self) -> MaskParams:
-        return MaskParams(self.T, self.P, int(self.is_prefill), self.s, self.lguess, self.gs, self.level_offset, self.dist_offset)
+        return MaskParams(self.T, self.P, int(self.is_prefill), self.s, self.lguess, self.gs, self.level_offset, self.dist_offset, self.layout)
 
 
 def _dev(t: torch.Tensor, name: str):

@@ -234,6 +234,25 @@ def build_step_layout(input_ids: Sequence[int], position_ids: Sequence[int], pas
                       is_prefill=past_tokens[1] is None, window=len(past_tokens[fill_level]))
 
 
+
+def flash_row_order(n_input: int, level_sizes: Sequence[int], lguess: int) -> List[int]:
+    """Row order the reference feeds its flash kernel (lade/models/modeling_llama.py:1471-1485, `swap_axis_for_flash`):
+    [inputs | L0 | levels >= 1 interleaved column-major | candidates].  Returns perm with perm[r_flash] = r_eager
+    (the index of the same token in the eager order [inputs | L0 | L1 | ... | candidates])."""
+    perm = list(range(n_input + level_sizes[0]))
+    base = n_input + level_sizes[0]
+    nl = len(level_sizes) - 1
+    if nl > 0:
+        s = level_sizes[1]
+        assert all(x == s for x in level_sizes[1:]), "the flash order needs equal level lengths (np.array(...).transpose())"
+        for w in range(s):
+            for l in range(nl):
+                perm.append(base + l * s + w)
+    T = n_input + sum(level_sizes) + lguess
+    perm += list(range(T - lguess, T))
+    return perm
+
+
 def mask_visible(q: int, c: int, T: int, s: int, lguess: int, gs: int, level_offset: int, dist_offset: int) -> bool:
     """Closed form of `j_make_causal_mask_multilevel` on the T x T new-token block
     (lade/models/modeling_llama.py:115-207); every row also sees all P cache columns (:204-205).

@@ -56,6 +56,59 @@ def test_mask_predicate_matches_reference_masks(lib):
     assert [format(int("".join("1" if b else "0" for b in r), 2), "x") for r in got.tolist()] == d["prefill_T9"]
 
 
+def test_mask_predicate_flash_row_order(lib):
+    """layout 1 (levels >= 1 column-major, the order of the reference's flash path): the rendered mask equals the
+    reference's dense mask with rows and new-token columns permuted by that order."""
+    from lookaheaddecoding_amd import ops
+    d = load("mask_cases.json")
+    n = 0
+    for c in d["cases"]:
+        ls = c["level_sizes"]
+        if len(ls) > 1 and any(x != ls[1] for x in ls[1:]):
+            continue
+        T, P = c["T"], c["P"]
+        n_input = c["level_offset"] + 1
+        perm = O.flash_row_order(n_input, ls, c["lguess"])
+        m0 = ops.StepMask(T=T, P=P, is_prefill=False, s=ls[-1], lguess=c["lguess"], gs=c["gs"], level_offset=c["level_offset"],
+                          dist_offset=1 + ls[0] - ls[-1])
+        m1 = ops.StepMask(T=T, P=P, is_prefill=False, s=ls[-1], lguess=c["lguess"], gs=c["gs"], level_offset=c["level_offset"],
+                          dist_offset=1 + ls[0] - ls[-1], layout=1)
+        eager = ops.mask_render(m0).cpu().numpy().astype(bool)
+        flash = ops.mask_render(m1).cpu().numpy().astype(bool)
+        cols = list(range(P)) + [P + p for p in perm]
+        assert np.array_equal(flash, eager[perm][:, cols]), c
+        n += 1
+    assert n > 100
+
+
+def test_attention_flash_row_order(lib):
+    """q rows, new K/V rows and output rows in the flash order: same numbers as the eager order, permuted."""
+    from lookaheaddecoding_amd import ops
+    torch.manual_seed(21)
+    for (n_input, ls, lguess, gs, P, H, Hkv, dh, dtype) in ((1, [14, 15, 15, 15], 60, 4, 300, 4, 4, 128, torch.bfloat16),
+                                                            (1, [6, 7, 7], 6, 3, 70, 8, 2, 64, torch.float16),
+                                                            (3, [5, 2, 2, 2], 8, 4, 33, 2, 2, 128, torch.float32)):
+        T = n_input + sum(ls) + lguess
+        S = P + T
+        S_max = (S + 63) // 64 * 64 + 64
+        perm = O.flash_row_order(n_input, ls, lguess)
+        lay = O.StepLayout(ids=[0] * T, positions=[], n_input=n_input, level_sizes=ls, lguess=lguess, is_prefill=False, window=ls[-1])
+        vis = O.dense_mask(lay, P, gs)
+        q = torch.randn(T, H, dh).to(dtype)
+        k = torch.randn(Hkv, S_max, dh).to(dtype)
+        v = torch.randn(Hkv, S_max, dh).to(dtype)
+        ref = O.attention_dense(q.float().transpose(0, 1), k.float()[:, :S], v.float()[:, :S], vis).transpose(0, 1).reshape(T, H * dh)
+        qf = q[perm]
+        kf, vf = k.clone(), v.clone()
+        kf[:, P:S] = k[:, [P + p for p in perm]]
+        vf[:, P:S] = v[:, [P + p for p in perm]]
+        m1 = ops.StepMask.from_levels(n_input, ls, lguess, gs, P, layout=1)
+        for ns in (1, 3):
+            out = ops.attn_fwd(qf.reshape(T, H * dh).cuda(), kf.cuda().contiguous(), vf.transpose(1, 2).contiguous().cuda(), m1, H=H, Hkv=Hkv, d=dh,
+                               n_splits=ns).float().cpu()
+            assert torch.allclose(out, ref[perm], **TOL[dtype]), (ls, ns, (out - ref[perm]).abs().max().item())
+
+
 # ---------------------------------------------------------------- attention
 
 def _layouts():

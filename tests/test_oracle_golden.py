@@ -68,6 +68,24 @@ def test_mask_closed_form_matches_reference():
     assert [format(int("".join("1" if b else "0" for b in r), 2), "x") for r in m.tolist()] == d["prefill_T9"]
 
 
+def test_flash_row_order_equals_the_reference_numpy_expression():
+    """oracle.flash_row_order vs the expression the reference uses to permute tokens for its flash kernel
+    (lade/models/modeling_llama.py:1483: np.append(all_past[0], np.array(all_past[1:]).transpose().flatten()))."""
+    for n_input, ls, lguess in ((1, [14, 15, 15, 15], 60), (1, [4, 5], 6), (3, [16, 17, 17], 0), (2, [6, 2, 2, 2], 8), (1, [9], 0)):
+        base = n_input
+        levels = []
+        for n in ls:
+            levels.append(list(range(base, base + n)))
+            base += n
+        if len(levels) > 1:
+            mid = np.append(np.array(levels[0]), np.array(levels[1:]).transpose().flatten()).tolist()
+        else:
+            mid = levels[0]
+        T = n_input + sum(ls) + lguess
+        want = list(range(n_input)) + [int(x) for x in mid] + list(range(T - lguess, T))
+        assert O.flash_row_order(n_input, ls, lguess) == want
+
+
 def _check_trace(res, run, rank_traces=None):
     assert res.tokens == run["tokens"]
     assert res.steps == run["steps"]
