@@ -322,6 +322,50 @@ def test_pool_kats_bit_exact(lib):
     assert n > 80
 
 
+def test_pool_churn_at_the_abi_limits_vs_oracle(lib):
+    """Randomised LRU churn with low-entropy tokens (duplicate keys inside one step, re-inserted n-grams, evictions) at the
+    ABI's limits - G = 64 slots, LEVEL = 16, windows up to 113 columns - after every op the whole device pool equals the
+    reference algorithm's dict (lade/decoding.py:37-127), and lookups return the same ordered candidates."""
+    from lookaheaddecoding_amd.cabi import MAX_GUESS_SET, MAX_LEVEL, MAX_WINDOW, call, ptr
+    rs = random.Random(2024)
+    n_ops = 0
+    for (N, W, G, vocab) in ((3, 1, 1, 2), (3, 7, 2, 2), (5, 15, 15, 3), (MAX_LEVEL, 20, MAX_GUESS_SET, 2), (4, MAX_WINDOW - 1, MAX_GUESS_SET, 5),
+                             (7, 20, 20, 4)):
+        gs, V, wcap = N - 1, 16, W + N
+        pool_tok = torch.zeros(V, G, gs, dtype=torch.int32, device="cuda")
+        pool_cnt = torch.zeros(V, dtype=torch.int32, device="cuda")
+        tm = {}
+        for it in range(25):
+            kind = rs.random()
+            if kind < 0.6:
+                past = [[rs.randrange(vocab) for _ in range(W - 1)]] + [[rs.randrange(vocab) for _ in range(W)] for _ in range(N - 2)]
+                new, lst = [rs.randrange(vocab) for _ in range(W)], rs.randrange(vocab)
+                O.update_token_map(tm, lst, past, new, N, W, G)
+                win = torch.zeros(N - 1, wcap, dtype=torch.int32)
+                for l, lv in enumerate(past):
+                    win[l, :len(lv)] = torch.tensor(lv, dtype=torch.int32)
+                call("lade_pool_insert_window", ptr(pool_tok), ptr(pool_cnt), V, G, gs, ptr(dev([lst])), ptr(dev(win)), wcap, ptr(dev(new)), W, N)
+            elif kind < 0.8:
+                toks = [rs.randrange(vocab) for _ in range(rs.randrange(0, 3 * N))]
+                O.fill_pool_with_prompt(toks, tm, N, G)
+                if toks:
+                    call("lade_pool_fill_prompt", ptr(pool_tok), ptr(pool_cnt), V, G, gs, ptr(dev(toks)), len(toks))
+            else:
+                toks = [rs.randrange(vocab) for _ in range(N)]
+                O.append_new_generated_pool(toks, tm, N, G)
+                call("lade_pool_insert_ngrams", ptr(pool_tok), ptr(pool_cnt), V, G, gs, ptr(dev(toks)), 1)
+            got = _pool_to_dict(pool_tok, pool_cnt)
+            want = {str(k): [list(t) for t in v] for k, v in tm.items() if len(v) > 0}
+            assert got == want, (N, W, G, vocab, it)
+            key = rs.randrange(vocab)
+            go = torch.zeros(G * gs, dtype=torch.int32, device="cuda"); gn = torch.zeros(1, dtype=torch.int32, device="cuda")
+            call("lade_pool_lookup", ptr(pool_tok), ptr(pool_cnt), V, G, gs, ptr(dev([key])), ptr(go), ptr(gn))
+            exp = O.pool_lookup(tm, key, True, G) or []
+            assert gn.item() == len(exp) // gs and go.cpu().tolist()[:len(exp)] == exp, (N, W, G, vocab, it, key)
+            n_ops += 1
+    assert n_ops == 150
+
+
 def test_pool_lookup_and_verify_vs_oracle(lib):
     from lookaheaddecoding_amd.cabi import call, ptr
     rs = random.Random(7)
