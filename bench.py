@@ -213,6 +213,20 @@ def main():
     avg_T = (sum(Ts) / len(Ts)) if Ts else float((N - 1) * W)
     P_end = run.P
 
+    # ---- the attention launch pair timed IN the step: a few more steady steps, eager, with a hipEvent before the
+    # attention launch and after the split merge of every layer (torch's current stream is the launch stream) ----
+    in_situ = None
+    if rank == 0 and not use_lp:
+        was_graph, run.use_graph = run.use_graph, False
+        eng.attn_events = []
+        for _ in range(4):
+            run.step()
+        sync()
+        evs, eng.attn_events, run.use_graph = eng.attn_events, None, was_graph
+        durs = sorted(e0.elapsed_time(e1) * 1e3 for (e0, e1, _, _) in evs)
+        if durs:
+            in_situ = {"us": sum(durs) / len(durs), "median_us": durs[len(durs) // 2], "T": evs[-1][2], "n_splits": evs[-1][3], "P": run.P, "launches": len(durs)}
+
     # ---- hot regime, measured last because it overwrites weights.  Random weights never accept a
     # candidate (S = 1).  To time the accept path under load the model is turned into a deterministic successor map:
     # every layer's o_proj / down_proj zeroed (the residual stream keeps the input embedding) and lm_head row j set to
@@ -255,14 +269,23 @@ def main():
         mask = ops.StepMask.from_levels(1, [W - 1] + [W] * (N - 2), g_mid * gs, gs, P_end)
         qkv = torch.randn(T_k, (cfg["heads"] + 2 * cfg["kv_heads"]) * cfg["head_dim"], device=dev).to(dtype)
         ns = eng.n_splits_for(T_k, P_end + T_k)
-        us = ops.time_attn(qkv, eng.k_cache(0), eng.vt_cache(0), mask, H=cfg["heads"], Hkv=cfg["kv_heads"], d=cfg["head_dim"],
-                           n_splits=ns, reps=200)
+        # every repetition uses the next layer's K/V cache (L caches of 2*Hkv*S_max*d*e bytes >> the 256 MB Infinity Cache), so
+        # the launch streams its keys/values from HBM exactly as inside a decode step
+        us = ops.time_attn(qkv, [eng.k_cache(li) for li in range(eng.L)], [eng.vt_cache(li) for li in range(eng.L)], mask,
+                           H=cfg["heads"], Hkv=cfg["kv_heads"], d=cfg["head_dim"], n_splits=ns, reps=max(200, 8 * eng.L))
+        us_iso = us
+        if in_situ is not None and in_situ["T"] == T_k:
+            us, ns = in_situ["us"], in_situ["n_splits"]
         alg = attn_algorithmic_bytes(cfg, T_k, P_end)
         achieved = alg / (us * 1e-6) / 1e9
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
                     "traffic": pmc_traffic(T_k, P_end, ns), "kernel": f"lade::attn_fwd_kernel<{args.dtype},{cfg['head_dim']}> (+combine, n_splits={ns})",
                     "launch_us": round(us, 2), "algorithmic_bytes": alg, "T": T_k, "P": P_end,
-                    "note": "one layer's launch pair (attention + split combine) timed with hipEvents on the launch stream (lade_time_attn, 200 reps) at the end-of-run shape"}
+                    "launch_us_in_step": None if in_situ is None else {k: (round(v, 2) if isinstance(v, float) else v) for k, v in in_situ.items()},
+                    "launch_us_isolated": round(us_iso, 2),
+                    "note": "launch_us = one layer's launch pair (attention + split merge) bracketed by hipEvents on the launch stream INSIDE real decode steps "
+                            "(4 eager steady steps after the timed region, every layer), mean; launch_us_isolated = the same pair launched back to back "
+                            "(lade_time_attn_rot, cycling through the layers' K/V caches so that every launch reads HBM)"}
         hot = hot_regime()
         cpu = None
         if not args.no_cpu_baseline and world == 1:            # the CPU baseline is timed at N=1 only

@@ -270,6 +270,9 @@ const char* lade_last_error_string(void);
 /* kernel timing helper for bench.py: runs `reps` launches of lade_attn_fwd (+combine) on `stream`
  * bracketed by hipEvents and returns the mean duration of one launch pair in microseconds. */
 int lade_time_attn(const lade_attn_args* a, int32_t reps, float* mean_us, void* stream);
+/* the same over n argument sets used round-robin (a[i % n] in repetition i): n K/V caches larger than the Infinity
+ * Cache in total make every launch stream from HBM, as consecutive layers of a decode step do */
+int lade_time_attn_rot(const lade_attn_args* a, int32_t n, int32_t reps, float* mean_us, void* stream);
 
 #ifdef __cplusplus
 }

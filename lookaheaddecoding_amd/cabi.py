@@ -83,6 +83,7 @@ SIGNATURES = {
     "lade_version": [],
     "lade_last_error_string": [],
     "lade_time_attn": [C.POINTER(AttnArgs), _i32, C.POINTER(C.c_float), _vp],
+    "lade_time_attn_rot": [C.POINTER(AttnArgs), _i32, _i32, C.POINTER(C.c_float), _vp],
 }
 
 

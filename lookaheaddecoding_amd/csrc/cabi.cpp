@@ -57,3 +57,37 @@ extern "C" int lade_time_attn(const lade_attn_args* a, int32_t reps, float* mean
     (void)hipEventDestroy(e1);
     return rc;
 }
+
+// Same measurement over `n` argument sets used round-robin (one launch pair per repetition): with n K/V caches whose
+// total size exceeds the 256 MB Infinity Cache every launch streams its keys/values from HBM, as a decode step does
+// (consecutive layers own different caches); with n = 1 the cache stays resident in the Infinity Cache.
+extern "C" int lade_time_attn_rot(const lade_attn_args* a, int32_t n, int32_t reps, float* mean_us, void* stream) {
+    LADE_REQUIRE(a && mean_us && reps > 0 && n > 0, LADE_E_ARG, "lade_time_attn_rot: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        lade::set_error("lade_time_attn_rot: hipEventCreate failed");
+        return LADE_E_LAUNCH;
+    }
+    int rc = 0;
+    for (int i = 0; i < n && rc == 0; ++i) {          // one untimed pass: validation, code objects, LDS attributes
+        rc = lade_attn_fwd(a + i, stream);
+        if (rc == 0 && a[i].n_splits > 1) rc = lade_attn_combine(a + i, stream);
+    }
+    if (rc == 0) {
+        (void)hipEventRecord(e0, st);
+        for (int i = 0; i < reps && rc == 0; ++i) {
+            const lade_attn_args* x = a + (i % n);
+            rc = lade_attn_fwd(x, stream);
+            if (rc == 0 && x->n_splits > 1) rc = lade_attn_combine(x, stream);
+        }
+        (void)hipEventRecord(e1, st);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        *mean_us = ms * 1000.f / (float)reps;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}

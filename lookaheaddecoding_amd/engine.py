@@ -78,6 +78,7 @@ class StepEngine:
         # KV cache: [L][2][Hkv*S_max*d]  (K: [Hkv][S_max][d], V: [Hkv][d][S_max]), zero-initialised
         self.kv = torch.zeros(self.L, 2, self.Hkv * self.S_max * self.d, dtype=dt, device=dev)
         self.kv._lade_meta = dict(Hkv=self.Hkv, d=self.d, S_max=self.S_max)
+        self.attn_events = None             # set to a list to collect (start, end, T, n_splits) hipEvent pairs per layer
         # workspaces (fixed addresses: graph-capturable, no allocator traffic in the loop)
         qkv_w = (self.H + 2 * self.Hkv) * self.d
         self.ws_x = torch.empty(max_T, self.hidden, dtype=dt, device=dev)
@@ -200,8 +201,16 @@ class StepEngine:
                 torch.matmul(h, lw["wqkv"].t(), out=qkv)
                 ops.rope_kv_append(qkv, pos, self.cos, self.sin, self.k_cache(li), self.vt_cache(li), P, H=H, Hkv=Hkv, d=d, dyn_P=dyn_P)
                 q_in = qkv
+            ev = self.attn_events
+            if ev is not None:              # bench.py: hipEvents around the attention launch pair, in the real step
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
             ops.attn_fwd(q_in, self.k_cache(li), self.vt_cache(li), mask, H=H, Hkv=Hkv, d=d, out=o, n_splits=n_splits,
                          part_o=self.part_o, part_ml=self.part_ml, dyn_P=dyn_P)
+            if ev is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                ev.append((e0, e1, mask.T, n_splits))
             if cfg_o:
                 ops.gemm_parts(o, lw["wo"], part, cfg_o[2], cfg_o[1], cfg_o[0])
                 ops.add_rmsnorm_parts(x, part, cfg_o[2], lw["ln2"], self.eps, out=h)      # x += attn; h = norm(x)

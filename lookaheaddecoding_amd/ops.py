@@ -89,17 +89,27 @@ def attn_fwd(q: torch.Tensor, k_cache: torch.Tensor, vt_cache: torch.Tensor, mas
 
 
 def time_attn(q, k_cache, vt_cache, mask: StepMask, *, H, Hkv, d, n_splits: int, reps: int = 20, debug_timeline: bool = False):
-    """Mean duration in microseconds of one attention launch (+combine), measured with hipEvents on the
-    launch stream inside the library."""
-    T, S_max = mask.T, k_cache.shape[1]
+    """Mean duration in microseconds of one attention launch (+combine), measured with hipEvents on the launch stream
+    inside the library.  k_cache / vt_cache may be LISTS of caches: they are used round-robin, one per repetition, so
+    that with enough of them (total > the 256 MB Infinity Cache) every launch streams its K/V from HBM like the
+    consecutive layers of a decode step; a single cache stays Infinity-Cache resident across repetitions."""
+    ks = list(k_cache) if isinstance(k_cache, (list, tuple)) else [k_cache]
+    vs = list(vt_cache) if isinstance(vt_cache, (list, tuple)) else [vt_cache]
+    assert len(ks) == len(vs)
+    T, S_max = mask.T, ks[0].shape[1]
     out = torch.empty(T, H * d, dtype=q.dtype, device=q.device)
     part_o = torch.empty(max(n_splits, 1), T, H, d, dtype=q.dtype, device=q.device)
     n_ml = max(n_splits, 1) * H * T * 2
     part_ml = torch.zeros(n_ml + 16 * 4096, dtype=torch.float32, device=q.device)   # + room for LADE_ATTN_DBG=16 timestamps
-    a = AttnArgs(ptr(q), ptr(k_cache), ptr(vt_cache), ptr(out), ptr(part_o), ptr(part_ml), None, q.stride(0), out.stride(0),
-                 H, Hkv, d, S_max, dtype_code(q), n_splits, 1.0 / math.sqrt(d), mask.c_struct())
+    arr = (AttnArgs * len(ks))()
+    for i, (k, v) in enumerate(zip(ks, vs)):
+        arr[i] = AttnArgs(ptr(q), ptr(k), ptr(v), ptr(out), ptr(part_o), ptr(part_ml), None, q.stride(0), out.stride(0),
+                          H, Hkv, d, S_max, dtype_code(q), n_splits, 1.0 / math.sqrt(d), mask.c_struct())
     us = C.c_float(0.0)
-    call("lade_time_attn", C.byref(a), reps, C.byref(us))
+    if len(ks) == 1:
+        call("lade_time_attn", C.byref(arr[0]), reps, C.byref(us))
+    else:
+        call("lade_time_attn_rot", arr, len(ks), reps, C.byref(us))
     if debug_timeline:
         torch.cuda.synchronize()
         return float(us.value), part_ml[n_ml:].view(torch.int64).view(-1, 8).cpu()
