@@ -126,16 +126,16 @@ class StepEngine:
         """(mb, bn, n_split) of the split-K GEMM for projection `name` at a step of M rows, or None when the library
         GEMM is faster.  Timed once per (projection, row class) on this GPU, rotating through the layers' weights so the
         stream comes from HBM rather than from the Infinity Cache."""
-        mclass = 64 if M <= 64 else 128
+        mclass = 64 if M <= 64 else (96 if M <= 96 else 128)
         key = (name, mclass)
         if key in self.gemm_cfg:
             return self.gemm_cfg[key]
         ws = [lw[name] for lw in self.layers]
         N, K = ws[0].shape
-        a = torch.randn(mclass if mclass == 128 else 60, K, device=self.device).to(self.dtype)
+        a = torch.randn({64: 60, 96: 92, 128: 128}[mclass], K, device=self.device).to(self.dtype)
         out = torch.empty(a.shape[0], N, dtype=self.dtype, device=self.device)
         cands = []
-        for mb, bns in (((2, (128, 256)),) if mclass == 64 else ((4, (64, 128, 192, 256)),)):
+        for mb, bns in {64: ((2, (128, 256)),), 96: ((3, (64, 128, 192, 256)), (4, (128, 192))), 128: ((4, (64, 128, 192, 256)),)}[mclass]:
             for bn in bns:
                 nblk = (N + bn - 1) // bn
                 for S in sorted({max(1, round(self.n_cu / nblk)), max(1, round(self.n_cu * 2 / nblk)), max(1, round(self.n_cu * 3 / nblk))}):

@@ -126,7 +126,7 @@ def test_skinny_gemm_vs_fp32_reference():
     for (M, N, K) in ((60, 4096, 4096), (120, 12288, 4096), (76, 4096, 11008), (1, 512, 128), (37, 264, 192)):
         a = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
         ref = a.float() @ w.float().t()
-        for (S, bn, mb) in ((1, 128, 0), (4, 128, 0), (3, 64, 4), (2, 256, 0)):
+        for (S, bn, mb) in ((1, 128, 0), (4, 128, 0), (3, 64, 4), (2, 256, 0), (2, 192, 3), (5, 64, 3), (1, 256, 3)):
             if K // 64 < S:
                 continue
             out = ops.gemm_skinny(a, w, n_split=S, bn=bn, mb=mb).float()
