@@ -2,7 +2,7 @@
 //
 // Reference: the nn.Linear projections of the step (q/k/v/o, gate/up/down, lm_head;
 // lade/models/modeling_llama.py:360-380, 492-494, 558, 1541) - SURVEY.md 8(f) rank 2.  With M = T <= 240 rows
-// the GEMM is a stream of the weight matrix: bound by HBM (and, per CU, by the ~25 GB/s a CU can ingest), so
+// the GEMM is a stream of the weight matrix: bound by HBM (and, per CU, by the ~55-68 GB/s one CU can ingest from HBM), so
 // the weight bytes must be spread over all 256 CUs.  Work-group = (BN weight rows) x (one K slice) x (one row
 // block); the weight tile and the activation tile of each 64-deep K step arrive by LDS-DMA into a 3-stage ring,
 // eight waves hold the C^T tile in MFMA accumulators (lane = one activation row, like the attention kernel),
