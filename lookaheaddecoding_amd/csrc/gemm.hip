@@ -221,7 +221,7 @@ static int launch_gemm(const GemmK& g, hipStream_t st) {
 using namespace lade;
 
 // bn: weight rows per work-group (64/128/192/256 with 96- or 128-row blocks; 32..256 with 64-row blocks); mb: 32-row
-// activation blocks per work-group (2 | 3 | 4; 0 = by M)
+// activation blocks per work-group (1 | 2 | 3 | 4; 0 = by M)
 extern "C" int lade_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, float* Cpart,
                                 int32_t M, int32_t N, int32_t K, int32_t n_split, int32_t bn, int32_t mb, int32_t dtype, void* stream) {
     LADE_REQUIRE(A && W && M > 0 && N > 0 && K > 0 && n_split >= 1, LADE_E_ARG, "lade_gemm_skinny: M=%d N=%d K=%d split=%d", M, N, K, n_split);
@@ -234,9 +234,15 @@ extern "C" int lade_gemm_skinny(const void* A, int64_t lda, const void* W, int64
     g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.n_split = n_split;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("LADE_GEMM_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
     hipStream_t st = (hipStream_t)stream;
+    const bool tiny_m = mb == 1 || (mb == 0 && M <= 32);
     const bool small_m = mb == 2 || (mb == 0 && M <= 64);
     const bool mid_m = mb == 3 || (mb == 0 && M > 64 && M <= 96);
 #define GO(TT)                                                                        \
+    if (tiny_m) {                          /* one 32-row block: lookahead-parallel ranks, config 1 (T <= 16) */ \
+        if (bn <= 64) return launch_gemm<TT, 1, 2, 1>(g, st);                         \
+        if (bn <= 128) return launch_gemm<TT, 1, 4, 1>(g, st);                        \
+        return launch_gemm<TT, 1, 8, 1>(g, st);                                       \
+    }                                                                                 \
     if (mid_m) {                           /* 96-row blocks: 6 computing waves */     \
         if (bn <= 64) return launch_gemm<TT, 3, 2, 1>(g, st);                         \
         if (bn <= 128) return launch_gemm<TT, 3, 2, 2>(g, st);                        \

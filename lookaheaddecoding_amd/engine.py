@@ -119,23 +119,25 @@ class StepEngine:
     def n_splits_for(self, T: int, S_tot: int) -> int:
         if self.dtype == torch.float32:
             return 1
-        return min(ops.choose_splits(self.H, self.H // self.Hkv, T, S_tot, self.n_cu), self.max_splits)
+        # always the split + merge form: the hipGraph steps are captured with it, and an eager step of the same
+        # sequence must round the same way (16-bit partials) for the two modes to produce the same token stream
+        return min(ops.choose_splits(self.H, self.H // self.Hkv, T, S_tot, self.n_cu, allow_single=False), self.max_splits)
 
     # ---- GEMM selection ---------------------------------------------------------------------------
     def _tune(self, name: str, M: int):
         """(mb, bn, n_split) of the split-K GEMM for projection `name` at a step of M rows, or None when the library
         GEMM is faster.  Timed once per (projection, row class) on this GPU, rotating through the layers' weights so the
         stream comes from HBM rather than from the Infinity Cache."""
-        mclass = 64 if M <= 64 else (96 if M <= 96 else 128)
+        mclass = 32 if M <= 32 else (64 if M <= 64 else (96 if M <= 96 else 128))
         key = (name, mclass)
         if key in self.gemm_cfg:
             return self.gemm_cfg[key]
         ws = [lw[name] for lw in self.layers]
         N, K = ws[0].shape
-        a = torch.randn({64: 60, 96: 92, 128: 128}[mclass], K, device=self.device).to(self.dtype)
+        a = torch.randn({32: 30, 64: 60, 96: 92, 128: 128}[mclass], K, device=self.device).to(self.dtype)
         out = torch.empty(a.shape[0], N, dtype=self.dtype, device=self.device)
         cands = []
-        for mb, bns in {64: ((2, (128, 256)),), 96: ((3, (64, 128, 192, 256)), (4, (128, 192))), 128: ((4, (64, 128, 192, 256)),)}[mclass]:
+        for mb, bns in {32: ((1, (64, 128, 256)), (2, (128,))), 64: ((2, (128, 256)),), 96: ((3, (64, 128, 192, 256)), (4, (128, 192))), 128: ((4, (64, 128, 192, 256)),)}[mclass]:
             for bn in bns:
                 nblk = (N + bn - 1) // bn
                 for S in sorted({max(1, round(self.n_cu / nblk)), max(1, round(self.n_cu * 2 / nblk)), max(1, round(self.n_cu * 3 / nblk))}):

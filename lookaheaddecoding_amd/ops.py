@@ -45,13 +45,13 @@ def _dev(t: torch.Tensor, name: str):
         raise cabi.LadeHipError(f"{name} must be a GPU tensor (the HIP path has no CPU fallback)")
 
 
-def choose_splits(H: int, n_rep: int, T: int, S_tot: int, n_cu: int = 256) -> int:
+def choose_splits(H: int, n_rep: int, T: int, S_tot: int, n_cu: int = 256, allow_single: bool = True) -> int:
     """KV splits of the lookahead attention.  One CU ingests only ~55-68 GB/s from HBM (tools/hbm_probe), so the
     grid (row blocks x KV heads x splits) should cover every CU once; a split is a whole number of 64-key
     tiles and no split may be empty."""
     blocks = (H // n_rep) * ((n_rep * T + 127) // 128)
     tiles = max(1, (S_tot + 63) // 64)
-    if tiles <= 5:                                # <= 320 keys: one work-group per head beats a second (merge) launch
+    if tiles <= 5 and allow_single:               # <= 320 keys: one work-group per head beats a second (merge) launch
         return 1                                  # (tools/attn_bench.py: 7.3-9.8 us vs 10.0-10.3 us at P = 64..256, T = 60)
     want = max(1, min(n_cu // max(blocks, 1), tiles, 32))
     tps = (tiles + want - 1) // want              # tiles per split

@@ -123,10 +123,10 @@ def test_argmax_fullsize_and_odd_vocab():
 def test_skinny_gemm_vs_fp32_reference():
     from lookaheaddecoding_amd import ops
     torch.manual_seed(4)
-    for (M, N, K) in ((60, 4096, 4096), (120, 12288, 4096), (76, 4096, 11008), (1, 512, 128), (37, 264, 192)):
+    for (M, N, K) in ((60, 4096, 4096), (120, 12288, 4096), (76, 4096, 11008), (1, 512, 128), (37, 264, 192), (16, 2048, 2048), (31, 4096, 4096)):
         a = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
         ref = a.float() @ w.float().t()
-        for (S, bn, mb) in ((1, 128, 0), (4, 128, 0), (3, 64, 4), (2, 256, 0), (2, 192, 3), (5, 64, 3), (1, 256, 3)):
+        for (S, bn, mb) in ((1, 128, 0), (4, 128, 0), (3, 64, 4), (2, 256, 0), (2, 192, 3), (5, 64, 3), (1, 256, 3), (3, 64, 1), (2, 128, 1), (4, 256, 1)):
             if K // 64 < S:
                 continue
             out = ops.gemm_skinny(a, w, n_split=S, bn=bn, mb=mb).float()

@@ -45,7 +45,7 @@ for M in [int(x) for x in os.environ.get('M', '60,120').split(',')]:
         t_ref = timeit(ref)
         res = []
         want = torch.matmul(a.float(), ws[0].float().t())
-        for mb, bn in ([(2, 32), (2, 64), (2, 128), (2, 256)] if M <= 64 else [(4, 64), (4, 128), (4, 192), (4, 256), (2, 64), (2, 128), (2, 256)]):
+        for mb, bn in ([(2, 32), (2, 64), (2, 128), (2, 256)] + ([(1, 64), (1, 128), (1, 256)] if M <= 32 else []) if M <= 64 else [(4, 64), (4, 128), (4, 192), (4, 256), (2, 64), (2, 128), (2, 256)]):
             for S in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16):
                 part = torch.empty(S, M, N, dtype=torch.float32, device="cuda") if S > 1 else None
 
