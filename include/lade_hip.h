@@ -33,8 +33,14 @@
  *                            lade/decoding.py:1023-1024, 1088-1107 (four pickled object collectives
  *                            -> one fixed int32 all-gather issued by the host through RCCL)
  *   lade_softmax_rows / lade_prob_gather   probs for the sampling verify  lade/decoding.py:484-489
- *   lade_rmsnorm / lade_silu_mul  LlamaRMSNorm / SwiGLU glue around the GEMMs
- *                            lade/models/modeling_llama.py:222-227, :360-380 ("next" row)
+ *   lade_rmsnorm / lade_add_rmsnorm / lade_silu_mul / lade_gather_rows   LlamaRMSNorm (+ residual add), SwiGLU,
+ *                            embedding / logits-row gather around the GEMMs
+ *                            lade/models/modeling_llama.py:222-227, :360-380, :1164 ("next" row)
+ *   lade_gemm_skinny / lade_splitk_reduce   the nn.Linear projections of the step at M = T <= 128 rows
+ *                            lade/models/modeling_llama.py:360-380 (MLP), :492-494, :558 (q/k/v/o)
+ *   lade_rope_kv_append_parts / lade_add_rmsnorm_parts / lade_silu_mul_parts   the same glue ops taking that
+ *                            GEMM's fp32 split-K partials as input (the reduction is fused into the consumer)
+ *   lade_time_attn / lade_time_attn_rot   hipEvent timing helpers for bench.py (no reference counterpart)
  */
 #ifndef LADE_HIP_H
 #define LADE_HIP_H
@@ -247,7 +253,7 @@ int lade_gather_rows(const void* src, const int32_t* idx, void* dst, int32_t row
 /* ---- skinny weight-streaming GEMM -------------------------------------
  * C[M,N] = A[M,K] . W[N,K]^T for the projections of a decode step (M = T <= ~256 rows), bf16 / f16, fp32 accumulate.
  * n_split == 1: writes C (model dtype).  n_split > 1: writes fp32 partials Cpart[n_split][M][N] (summed in split
- * order - deterministic - by lade_splitk_reduce).  bn = weight rows per work-group (64..256), mb = 32-row activation
+ * order - deterministic - by lade_splitk_reduce).  bn = weight rows per work-group (32..256), mb = 32-row activation
  * blocks per work-group (2: 64 rows, 4: 128 rows, 0: by M).  K % 64 == 0. */
 int lade_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, float* Cpart,
                      int32_t M, int32_t N, int32_t K, int32_t n_split, int32_t bn, int32_t mb, int32_t dtype, void* stream);
