@@ -419,7 +419,8 @@ def gen_e2e_lp():
     port = 29611
     for (mname, pname, W, N, G, new, seed, R, pfp) in [("tiny-d16", "rep", 5, 4, 5, 48, 1, 2, 0), ("tiny-d16", "rep", 5, 4, 5, 48, 1, 3, 0),
                                                        ("tiny-d64", "rep2", 7, 5, 7, 40, 1, 2, 0), ("tiny-d64", "rep", 5, 3, 3, 40, 2, 4, 0),
-                                                       ("tiny-d16", "rep", 5, 4, 5, 48, 3, 2, 1), ("tiny-d64", "rep2", 6, 4, 4, 40, 2, 3, 1)]:
+                                                       ("tiny-d16", "rep", 5, 4, 5, 48, 3, 2, 1), ("tiny-d64", "rep2", 6, 4, 4, 40, 2, 3, 1),
+                                                       ("tiny-d64", "rep", 15, 5, 15, 40, 1, 8, 0)]:   # BASELINE config 5's W/N/G over 8 ranks
         cfg = make_config(mname)
         prompt = [t % cfg["vocab"] for t in PROMPTS[pname]]
         ctx = mp.get_context("spawn")

@@ -83,7 +83,7 @@ def _greedy_lp_patched(parallel, dec, run, be, ex, rank):
                               all_gather=lambda out, inp: ex.all_gather(rank, out, inp))
 
 
-@pytest.mark.parametrize("idx", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("idx", [0, 1, 2, 3, 4, 5, 6])
 def test_lp_hip_kernels_match_reference_gloo_runs(idx):
     with open(os.path.join(GOLDEN, "e2e_lp.json")) as f:
         run = json.load(f)["runs"][idx]

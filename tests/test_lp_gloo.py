@@ -61,7 +61,7 @@ def _worker(rank, R, port, run, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("idx", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("idx", [0, 1, 2, 3, 4, 5, 6])
 def test_lp_orchestration_matches_reference_gloo_runs(idx):
     with open(os.path.join(GOLDEN, "e2e_lp.json")) as f:
         runs = json.load(f)["runs"]
