@@ -32,7 +32,7 @@
  *   lade_lp_pack / lade_lp_reduce_apply   the per-step lookahead-parallel exchange record
  *                            lade/decoding.py:1023-1024, 1088-1107 (four pickled object collectives
  *                            -> one fixed int32 all-gather issued by the host through RCCL)
- *   lade_softmax_rows / lade_prob_gather   probs for the sampling verify  lade/decoding.py:484-489
+ *   lade_softmax_rows        fp32 probabilities of the sampling verify (temperature applied)  lade/decoding.py:484-489
  *   lade_rmsnorm / lade_add_rmsnorm / lade_silu_mul / lade_gather_rows   LlamaRMSNorm (+ residual add), SwiGLU,
  *                            embedding / logits-row gather around the GEMMs
  *                            lade/models/modeling_llama.py:222-227, :360-380, :1164 ("next" row)
@@ -149,7 +149,8 @@ int lade_rope_kv_append(void* qkv, const int32_t* positions, const void* cos_tab
 
 /* Copies `cnt` K/V rows src..src+cnt -> dst..dst+cnt in every layer of a [L][2] cache whose
  * K part is [Hkv][S_max][d] and V part [Hkv][d][S_max]; layer_stride / v_offset in elements.
- * If `ctl` is non-null, (src,dst,cnt) are read from ctl[LADE_CTL_KV_SRC..KV_CNT] on the device. */
+ * If `ctl` is non-null, (src,dst,cnt) are read from ctl[LADE_CTL_KV_SRC..KV_CNT] on the device.  max_cnt is reserved
+ * (pass 0). */
 int lade_kv_commit(void* cache, int64_t layer_stride, int64_t v_offset, int32_t L, int32_t Hkv, int32_t d,
                    int32_t S_max, int32_t src, int32_t dst, int32_t cnt, const int32_t* ctl, int32_t max_cnt,
                    int32_t elem_bytes, void* stream);
