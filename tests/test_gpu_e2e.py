@@ -124,6 +124,30 @@ def test_graph_mode_bf16_equals_eager_mode():
     assert [t["max_hit"] for t in a.trace] == [t["max_hit"] for t in b.trace]
 
 
+def test_long_generation_equals_plain_greedy_and_the_oracle_fp32():
+    """1200 new tokens (graph and eager mode): thousands of pool inserts with evictions, every candidate bucket, a KV
+    cache that grows past several attention-split regimes - the stream must stay the plain greedy stream, and the first
+    200 tokens and their step count must be the CPU oracle's (the oracle is pinned to the reference)."""
+    from lookaheaddecoding_amd.decoding import LookaheadDecoder
+    cfg, w, eng = make_engine("tiny-d64", torch.float32, 1, 0.05, max_seq=2048)
+    prompt = [1, 5, 9, 17, 33, 5, 9, 17, 44, 5, 9, 2, 5, 9]
+    n_new = 1200
+    plain = eng.plain_greedy(prompt, len(prompt) + n_new)
+    outs = []
+    for use_graph in (False, True):
+        dec = LookaheadDecoder(eng, 7, 5, 7, pool_from_prompt=True, use_graph=use_graph)
+        out = dec.greedy(prompt, len(prompt) + n_new, rng=random.Random(3), keep_trace=True)
+        assert out.tokens == plain, use_graph
+        assert out.steps < n_new            # the pool does hit on this repetitive stream
+        outs.append(out)
+    assert outs[0].steps == outs[1].steps and [t["max_hit"] for t in outs[0].trace] == [t["max_hit"] for t in outs[1].trace]
+    model = O.OracleLlama(cfg, {k: torch.as_tensor(v) for k, v in w.items()})
+    ref = O.lookahead_greedy(model, prompt, 7, 5, 7, len(prompt) + 200, random.Random(3), pool_from_prompt=True, keep_trace=True)
+    assert ref.tokens == plain[:len(ref.tokens)]
+    n_ref = ref.steps
+    assert [t["max_hit"] for t in outs[0].trace[:n_ref - 1]] == [t.max_hit for t in ref.trace[:n_ref - 1]]
+
+
 def test_sampling_fp32_identical_tokens_vs_reference():
     """jacobi_sample_multilevel parity: same python/torch RNG order, probabilities from the HIP step in fp32 ->
     the reference's sampled token ids and step counts (temperature / top-k / top-p runs)."""
