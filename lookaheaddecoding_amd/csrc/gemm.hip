@@ -50,12 +50,16 @@ struct GemmK {
     int dbg;               // ablation switches for tools/gemm_ablate.py (LADE_GEMM_DBG): 1 = no output stores, 4 = no LDS reads / MFMA
 };
 
-// MB = 32-row activation blocks per work-group (2 or 4); NG = weight-row groups (MB*NG <= 8 waves compute, all 8
-// waves issue DMA); NT = 32-row weight tiles per wave.  waves: m-block = w % MB, n-group = w / MB;
-// BN = 32 * NT * NG weight rows per work-group.
-template <typename T, int MB, int NG, int NT>
+// Work-group tile = BM activation rows x BN weight rows, BM = 32*MW*MT, BN = 32*NG*NT: the waves form an MW x NG grid
+// (MW*NG <= 8 waves compute, all 8 issue DMA; m-group = w % MW, n-group = w / MW) and one wave owns MT x NT MFMA tiles
+// of 32 x 32.  Per 16-deep K step a wave reads MT activation + NT weight fragments from LDS for MT*NT MFMAs, so the LDS
+// bytes read per weight byte are 8 waves * (MT + NT) / (NG*NT) ... = (MT + NT) / NT * MW (+ the DMA write): with MT = 1 a
+// 128-row step moves ~7 LDS bytes per weight byte and the 128 B/clk LDS port caps a CU at ~38 GB/s of weights; 2 x 2
+// wave tiles bring that to ~5.5.
+template <typename T, int MW, int MT, int NG, int NT>
 __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
-    static_assert(MB * NG <= 8, "at most 8 computing waves");
+    static_assert(MW * NG <= 8, "at most 8 computing waves");
+    constexpr int MB = MW * MT;
     constexpr int BN = 32 * NT * NG;
     constexpr int BM = 32 * MB;
     constexpr int W_BYTES = BN * 128, A_BYTES = BM * 128, STAGE = W_BYTES + A_BYTES;
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mb = wave % MB, ng = wave / MB;
+    const int mw = wave % MW, ng = wave / MW;
     const bool computes = ng < NG;
     const int ql = lane & 31, hi = lane >> 5;
     const int n0 = blockIdx.x * BN, split = blockIdx.y, m0 = blockIdx.z * BM;
@@ -99,11 +103,13 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
     for (int s = 0; s < G_NSTAGE; ++s)
         if (s < nt) issue(t0 + s, s);
 
-    f32x16 acc[NT];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][i][e] = 0.f;
 
     for (int i = 0; i < nt; ++i) {
         const int stage = i % G_NSTAGE;
@@ -117,12 +123,15 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
         if (computes && !(g.dbg & 4))
 #pragma unroll
         for (int kk = 0; kk < G_BK / 16; ++kk) {
-            const u32x4 af = *reinterpret_cast<const u32x4*>(as + g_off(mb * 32 + ql, kk * 2 + hi));
-            u32x4 wf[NT];
+            u32x4 af[MT], wf[NT];
+#pragma unroll
+            for (int a = 0; a < MT; ++a) af[a] = *reinterpret_cast<const u32x4*>(as + g_off((mw * MT + a) * 32 + ql, kk * 2 + hi));
 #pragma unroll
             for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const u32x4*>(ws + g_off((ng * NT + j) * 32 + ql, kk * 2 + hi));
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j] = GMfma<T>::run(wf[j], af, acc[j]);
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[a][j] = GMfma<T>::run(wf[j], af[a], acc[a][j]);
         }
         if (i + G_NSTAGE < nt) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -134,21 +143,22 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
     // ---- epilogue: C^T tile (lane = activation row ql of block mb, 16 weight rows per MFMA tile) -> row-major C ----
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     g_barrier();
-    const int m = m0 + mb * 32 + ql;
-    if ((g.dbg & 1) && acc[0][0] != 12345.678f) return;
+    if ((g.dbg & 1) && acc[0][0][0] != 12345.678f) return;
     if (g.n_split == 1) {
         // stage [BM][BN] in the model dtype, then whole-row 16-byte stores
         constexpr int RS = BN * 2 + 16;
         unsigned char* stg = smem;
         if (computes)
 #pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 u32x2 w;
-                w[0] = pack2<T>(acc[j][4 * g4 + 0], acc[j][4 * g4 + 1]);
-                w[1] = pack2<T>(acc[j][4 * g4 + 2], acc[j][4 * g4 + 3]);
-                *reinterpret_cast<u32x2*>(stg + (mb * 32 + ql) * RS + ((ng * NT + j) * 32 + 8 * g4 + 4 * hi) * 2) = w;
+                w[0] = pack2<T>(acc[a][j][4 * g4 + 0], acc[a][j][4 * g4 + 1]);
+                w[1] = pack2<T>(acc[a][j][4 * g4 + 2], acc[a][j][4 * g4 + 3]);
+                *reinterpret_cast<u32x2*>(stg + ((mw * MT + a) * 32 + ql) * RS + ((ng * NT + j) * 32 + 8 * g4 + 4 * hi) * 2) = w;
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         g_barrier();
@@ -166,11 +176,13 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
         static_assert((size_t)BM * RSF <= (size_t)G_NSTAGE * STAGE, "fp32 staging must fit in the ring");
         if (computes)
 #pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4)
-                *reinterpret_cast<float4*>(stg + (mb * 32 + ql) * RSF + ((ng * NT + j) * 32 + 8 * g4 + 4 * hi) * 4) =
-                    float4{acc[j][4 * g4 + 0], acc[j][4 * g4 + 1], acc[j][4 * g4 + 2], acc[j][4 * g4 + 3]};
+                *reinterpret_cast<float4*>(stg + ((mw * MT + a) * 32 + ql) * RSF + ((ng * NT + j) * 32 + 8 * g4 + 4 * hi) * 4) =
+                    float4{acc[a][j][4 * g4 + 0], acc[a][j][4 * g4 + 1], acc[a][j][4 * g4 + 2], acc[a][j][4 * g4 + 3]};
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         g_barrier();
         constexpr int CPR = BN * 4 / 16;
@@ -180,7 +192,6 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
                 *reinterpret_cast<float4*>(outp + (size_t)(m0 + row) * g.N + n0 + c * 4) = *reinterpret_cast<const float4*>(stg + row * RSF + c * 16);
         }
     }
-    (void)m;
 }
 
 // sums the n_split fp32 partials in split order and writes the model dtype:  C[m][n] = sum_s part[s][m][n]
@@ -200,71 +211,83 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, u
     *reinterpret_cast<u32x2*>(C + (size_t)m * ldc + i) = w;
 }
 
-template <typename T, int MB, int NG, int NT>
+template <typename T, int MW, int MT, int NG, int NT>
 static int launch_gemm(const GemmK& g, hipStream_t st) {
-    constexpr int BN = 32 * NT * NG, BM = 32 * MB;
+    constexpr int BN = 32 * NT * NG, BM = 32 * MW * MT;
     constexpr size_t lds = (size_t)G_NSTAGE * (BN + BM) * 128;
+    static_assert(lds <= 160 * 1024, "LDS ring too large");
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<T, MB, NG, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<T, MW, MT, NG, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     dim3 grid(cdiv(g.N, BN), g.n_split, cdiv(g.M, BM));
-    hipLaunchKernelGGL((gemm_skinny_kernel<T, MB, NG, NT>), grid, dim3(G_THREADS), lds, st, g);
+    hipLaunchKernelGGL((gemm_skinny_kernel<T, MW, MT, NG, NT>), grid, dim3(G_THREADS), lds, st, g);
     return check_launch("lade_gemm_skinny");
 }
-
-
 
 }  // namespace lade
 
 using namespace lade;
 
-// bn: weight rows per work-group (64/128/192/256 with 96- or 128-row blocks; 32..256 with 64-row blocks); mb: 32-row
-// activation blocks per work-group (1 | 2 | 3 | 4; 0 = by M)
+// bn: weight rows per work-group (32..256); mb: 32-row activation blocks per work-group (1 | 2 | 3 | 4; 0 = by M); mt: m-blocks
+// per wave (1 | 2 | 4; must divide mb): the waves form an (mb/mt) x NG grid with NG = min(8 / (mb/mt), bn/32) n-groups
 extern "C" int lade_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, float* Cpart,
-                                int32_t M, int32_t N, int32_t K, int32_t n_split, int32_t bn, int32_t mb, int32_t dtype, void* stream) {
+                                int32_t M, int32_t N, int32_t K, int32_t n_split, int32_t bn, int32_t mb, int32_t mt, int32_t dtype,
+                                void* stream) {
     LADE_REQUIRE(A && W && M > 0 && N > 0 && K > 0 && n_split >= 1, LADE_E_ARG, "lade_gemm_skinny: M=%d N=%d K=%d split=%d", M, N, K, n_split);
     LADE_REQUIRE(K % G_BK == 0 && lda % 8 == 0 && ldw % 8 == 0 && N % 8 == 0, LADE_E_ARG,
                  "lade_gemm_skinny: K=%d must be a multiple of %d, strides / N multiples of 8", K, G_BK);
     LADE_REQUIRE(n_split == 1 ? (C != nullptr && ldc % 8 == 0) : (Cpart != nullptr), LADE_E_ARG, "lade_gemm_skinny: missing output buffer");
     LADE_REQUIRE(dtype == LADE_BF16 || dtype == LADE_F16, LADE_E_DTYPE, "lade_gemm_skinny: dtype=%d", dtype);
+    if (mb == 0) mb = M <= 32 ? 1 : (M <= 64 ? 2 : (M <= 96 ? 3 : 4));
+    if (mt == 0) mt = 1;
+    LADE_REQUIRE(mb >= 1 && mb <= 4 && (mt == 1 || mt == 2 || mt == 4) && mb % mt == 0, LADE_E_ARG, "lade_gemm_skinny: mb=%d mt=%d", mb, mt);
     GemmK g;
     g.A = (const uint16_t*)A; g.W = (const uint16_t*)W; g.C = (uint16_t*)C; g.Cpart = Cpart;
     g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.n_split = n_split;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("LADE_GEMM_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
     hipStream_t st = (hipStream_t)stream;
-    const bool tiny_m = mb == 1 || (mb == 0 && M <= 32);
-    const bool small_m = mb == 2 || (mb == 0 && M <= 64);
-    const bool mid_m = mb == 3 || (mb == 0 && M > 64 && M <= 96);
-#define GO(TT)                                                                        \
-    if (tiny_m) {                          /* one 32-row block: lookahead-parallel ranks, config 1 (T <= 16) */ \
-        if (bn <= 64) return launch_gemm<TT, 1, 2, 1>(g, st);                         \
-        if (bn <= 128) return launch_gemm<TT, 1, 4, 1>(g, st);                        \
-        return launch_gemm<TT, 1, 8, 1>(g, st);                                       \
-    }                                                                                 \
-    if (mid_m) {                           /* 96-row blocks: 6 computing waves */     \
-        if (bn <= 64) return launch_gemm<TT, 3, 2, 1>(g, st);                         \
-        if (bn <= 128) return launch_gemm<TT, 3, 2, 2>(g, st);                        \
-        if (bn <= 192) return launch_gemm<TT, 3, 2, 3>(g, st);                        \
-        return launch_gemm<TT, 3, 2, 4>(g, st);                                       \
-    }                                                                                 \
-    if (small_m) {                                                                    \
-        if (bn <= 32) return launch_gemm<TT, 2, 1, 1>(g, st);                         \
-        if (bn <= 64) return launch_gemm<TT, 2, 2, 1>(g, st);                         \
-        if (bn <= 128) return launch_gemm<TT, 2, 4, 1>(g, st);                        \
-        return launch_gemm<TT, 2, 4, 2>(g, st);                                       \
-    } else {                                                                          \
-        if (bn <= 32) return launch_gemm<TT, 4, 1, 1>(g, st);                         \
-        if (bn <= 64) return launch_gemm<TT, 4, 2, 1>(g, st);                         \
-        if (bn <= 128) return launch_gemm<TT, 4, 2, 2>(g, st);                        \
-        if (bn <= 192) return launch_gemm<TT, 4, 2, 3>(g, st);                        \
-        return launch_gemm<TT, 4, 2, 4>(g, st);                                       \
+    const int nt32 = bn <= 32 ? 1 : (bn <= 64 ? 2 : (bn <= 128 ? 4 : (bn <= 192 ? 6 : 8)));      // 32-row weight tiles per work-group
+    // (MW, MT) families; within one, the weight tiles are spread over as many n-groups as there are waves left
+#define FAM_MW1(TT, MTv)   /* MW = 1: up to 8 n-groups */                                  \
+    switch (nt32) {                                                                         \
+        case 1: return launch_gemm<TT, 1, MTv, 1, 1>(g, st);                               \
+        case 2: return launch_gemm<TT, 1, MTv, 2, 1>(g, st);                               \
+        case 4: return launch_gemm<TT, 1, MTv, 4, 1>(g, st);                               \
+        case 6: return launch_gemm<TT, 1, MTv, 6, 1>(g, st);                               \
+        default: return launch_gemm<TT, 1, MTv, 8, 1>(g, st);                              \
     }
+#define FAM_MW2(TT, MTv)   /* MW = 2: up to 4 n-groups */                                  \
+    switch (nt32) {                                                                         \
+        case 1: return launch_gemm<TT, 2, MTv, 1, 1>(g, st);                               \
+        case 2: return launch_gemm<TT, 2, MTv, 2, 1>(g, st);                               \
+        case 4: return launch_gemm<TT, 2, MTv, 4, 1>(g, st);                               \
+        case 6: return launch_gemm<TT, 2, MTv, 3, 2>(g, st);                               \
+        default: return launch_gemm<TT, 2, MTv, 4, 2>(g, st);                              \
+    }
+#define FAM_MW34(TT, MWv)  /* MW = 3 | 4, MT = 1: 2 n-groups */                            \
+    switch (nt32) {                                                                         \
+        case 1: return launch_gemm<TT, MWv, 1, 1, 1>(g, st);                               \
+        case 2: return launch_gemm<TT, MWv, 1, 2, 1>(g, st);                               \
+        case 4: return launch_gemm<TT, MWv, 1, 2, 2>(g, st);                               \
+        case 6: return launch_gemm<TT, MWv, 1, 2, 3>(g, st);                               \
+        default: return launch_gemm<TT, MWv, 1, 2, 4>(g, st);                              \
+    }
+#define GO(TT)                                                                              \
+    if (mb == 1) { FAM_MW1(TT, 1) }                                                         \
+    if (mb == 2 && mt == 1) { FAM_MW2(TT, 1) }                                              \
+    if (mb == 2 && mt == 2) { FAM_MW1(TT, 2) }                                              \
+    if (mb == 3) { FAM_MW34(TT, 3) }                                                        \
+    if (mb == 4 && mt == 1) { FAM_MW34(TT, 4) }                                             \
+    if (mb == 4 && mt == 2) { FAM_MW2(TT, 2) }                                              \
+    { FAM_MW1(TT, 4) }
     if (dtype == LADE_BF16) { GO(BF16) } else { GO(F16) }
 #undef GO
+#undef FAM_MW1
+#undef FAM_MW2
+#undef FAM_MW34
 }
-
 
 extern "C" int lade_splitk_reduce(const float* part, void* C, int64_t ldc, int32_t M, int32_t N, int32_t n_split, int32_t dtype, void* stream) {
     LADE_REQUIRE(part && C && M > 0 && N > 0 && N % 4 == 0 && n_split >= 1, LADE_E_ARG, "lade_splitk_reduce: bad args");

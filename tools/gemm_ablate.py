@@ -14,9 +14,10 @@ def timeit(fn, reps=50):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / reps
-M = 60
+M = int(os.environ.get('M', '60'))
+MB = 2 if M <= 64 else 4
 dbg = os.environ.get('LADE_GEMM_DBG', '0')
-for name, N, K, cfgs in (("qkv", 12288, 4096, [(2, 128, 5), (2, 256, 4)]), ("gate_up", 22016, 4096, [(2, 128, 4), (2, 256, 5), (2,128,2)]), ("down", 4096, 11008, [(2, 128, 8)])):
+for name, N, K, cfgs in (("qkv", 12288, 4096, [(MB, 128, 5), (MB, 256, 4), (MB, 192, 4)]), ("gate_up", 22016, 4096, [(MB, 128, 4), (MB, 256, 5), (MB, 192, 2)]), ("down", 4096, 11008, [(MB, 128, 8)])):
     a = torch.randn(M, K, device="cuda").bfloat16()
     ws = [torch.randn(N, K, device="cuda").bfloat16() * 0.02 for _ in range(max(1, int(600e6 / (N * K * 2))))]
     i = [0]
@@ -24,6 +25,6 @@ for name, N, K, cfgs in (("qkv", 12288, 4096, [(2, 128, 5), (2, 256, 4)]), ("gat
         part = torch.empty(S, M, N, dtype=torch.float32, device="cuda")
         def mine():
             i[0] = (i[0] + 1) % len(ws)
-            call('lade_gemm_skinny', ptr(a), a.stride(0), ptr(ws[i[0]]), ws[i[0]].stride(0), None, 0, ptr(part), M, N, K, S, bn, mb, dtype_code(a))
+            call('lade_gemm_skinny', ptr(a), a.stride(0), ptr(ws[i[0]]), ws[i[0]].stride(0), None, 0, ptr(part), M, N, K, S, bn, mb, int(os.environ.get('PIPE', '0')), dtype_code(a))
         t = timeit(mine)
         print(f"dbg={dbg:>2s} {name:8s} bn={bn:3d} S={S:2d}  {t:7.2f} us  {N * K * 2 / t / 1e6:5.2f} TB/s", flush=True)

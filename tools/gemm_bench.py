@@ -45,7 +45,10 @@ for M in [int(x) for x in os.environ.get('M', '60,120').split(',')]:
         t_ref = timeit(ref)
         res = []
         want = torch.matmul(a.float(), ws[0].float().t())
-        for mb, bn in ([(2, 32), (2, 64), (2, 128), (2, 256)] + ([(1, 64), (1, 128), (1, 256)] if M <= 32 else []) if M <= 64 else [(4, 64), (4, 128), (4, 192), (4, 256), (2, 64), (2, 128), (2, 256)]):
+        shapes_ = ([(2, 1, 32), (2, 1, 64), (2, 1, 128), (2, 1, 256), (2, 2, 128), (2, 2, 192), (2, 2, 256)] + ([(1, 1, 64), (1, 1, 128), (1, 1, 256)] if M <= 32 else [])
+                   if M <= 64 else [(4, 1, 64), (4, 1, 128), (4, 1, 192), (4, 1, 256), (4, 2, 128), (4, 2, 192), (4, 2, 256), (4, 4, 128), (4, 4, 192), (4, 4, 256)]
+                   + ([(3, 1, 128), (3, 1, 192)] if M <= 96 else []))
+        for mb, MT, bn in shapes_:
             for S in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16):
                 part = torch.empty(S, M, N, dtype=torch.float32, device="cuda") if S > 1 else None
 
@@ -53,18 +56,19 @@ for M in [int(x) for x in os.environ.get('M', '60,120').split(',')]:
                     i[0] = (i[0] + 1) % len(ws)
                     if NO_REDUCE and S > 1:
                         from lookaheaddecoding_amd.cabi import call, ptr, dtype_code
-                        call('lade_gemm_skinny', ptr(a), a.stride(0), ptr(ws[i[0]]), ws[i[0]].stride(0), ptr(out), out.stride(0), ptr(part), M, N, K, S, bn, mb, dtype_code(a))
+                        call('lade_gemm_skinny', ptr(a), a.stride(0), ptr(ws[i[0]]), ws[i[0]].stride(0), ptr(out), out.stride(0), ptr(part), M, N, K, S, bn, mb, MT, dtype_code(a))
                     else:
-                        ops.gemm_skinny(a, ws[i[0]], out=out, n_split=S, bn=bn, part=part, mb=mb)
+                        ops.gemm_skinny(a, ws[i[0]], out=out, n_split=S, bn=bn, part=part, mb=mb, mt=MT)
 
                 try:
-                    got = ops.gemm_skinny(a, ws[0], n_split=S, bn=bn, mb=mb).float()
+                    got = ops.gemm_skinny(a, ws[0], n_split=S, bn=bn, mb=mb, mt=MT).float()
                     err = (got - want).abs().max().item()
                     t = timeit(mine)
-                    res.append((t, f"{mb}x{bn}", S, err))
+                    res.append((t, f"{mb}.{MT}x{bn}", S, err))
                 except Exception as ex:
-                    res.append((float("inf"), f"{mb}x{bn}", S, 0.0))
+                    res.append((float("inf"), f"{mb}.{MT}x{bn}", S, 0.0))
         res.sort(key=lambda x: x[0])
+        assert max(r[3] for r in res) < 0.2, max(res, key=lambda r: r[3])
         mb = N * K * 2 / 1e6
         best = res[0]
         print(f"M={M:3d} {name:8s} N={N:5d} K={K:5d}  W={mb:6.1f} MB  torch {t_ref:7.2f} us ({mb / t_ref:5.2f} TB/s) | best mine {best[0]:7.2f} us "
