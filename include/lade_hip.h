@@ -255,11 +255,12 @@ int lade_gather_rows(const void* src, const int32_t* idx, void* dst, int32_t row
  * C[M,N] = A[M,K] . W[N,K]^T for the projections of a decode step (M = T <= ~256 rows), bf16 / f16, fp32 accumulate.
  * n_split == 1: writes C (model dtype).  n_split > 1: writes fp32 partials Cpart[n_split][M][N] (summed in split
  * order - deterministic - by lade_splitk_reduce).  bn = weight rows per work-group (32..256), mb = 32-row activation
- * blocks per work-group (1: 32 rows, 2: 64, 3: 96, 4: 128, 0: by M; larger M runs as several row blocks).  mt = 32-row activation blocks per WAVE (0 | 1 | 2 | 4,
- * divides mb): larger wave tiles re-read less from LDS per weight byte (the LDS port bounds wide steps).  K % 64 == 0. */
+ * blocks per work-group (1: 32 rows, 2: 64, 3: 96, 4: 128, 0: by M; larger M runs as several row blocks).  mt = 32-row activation blocks per WAVE (0 | 1..4, divides
+ * mb) and nt = 32-row weight tiles per wave (0 = fewest): the waves form an (mb/mt) x (bn/32/nt) grid; larger wave tiles
+ * re-read less from LDS per weight byte.  Unsupported shapes return LADE_E_ARG.  K % 64 == 0. */
 int lade_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, float* Cpart,
-                     int32_t M, int32_t N, int32_t K, int32_t n_split, int32_t bn, int32_t mb, int32_t mt, int32_t dtype,
-                     void* stream);
+                     int32_t M, int32_t N, int32_t K, int32_t n_split, int32_t bn, int32_t mb, int32_t mt, int32_t nt,
+                     int32_t dtype, void* stream);
 /* consumers that take a GEMM output as n_parts fp32 split-K partials [n_parts][rows][width] (part_stride elements
  * apart), sum them in split order and round once to the model dtype - so the split-K GEMM needs no reduce pass */
 int lade_add_rmsnorm_parts(void* x, const float* parts, int32_t n_parts, int64_t part_stride, const void* weight, void* y,

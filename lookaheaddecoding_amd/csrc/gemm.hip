@@ -230,11 +230,12 @@ static int launch_gemm(const GemmK& g, hipStream_t st) {
 
 using namespace lade;
 
-// bn: weight rows per work-group (32..256); mb: 32-row activation blocks per work-group (1 | 2 | 3 | 4; 0 = by M); mt: m-blocks
-// per wave (1 | 2 | 4; must divide mb): the waves form an (mb/mt) x NG grid with NG = min(8 / (mb/mt), bn/32) n-groups
+// bn: weight rows per work-group (32..256); mb: 32-row activation blocks per work-group (1..4; 0 = by M); mt: m-blocks per
+// wave (1 | 2 | 3 | 4, divides mb; 0 = 1); nt: 32-row weight tiles per wave (1..4; 0 = spread the tiles over as many n-groups
+// as there are waves).  The waves form an (mb/mt) x (bn/32/nt) grid.  Only the shapes in the table below are built.
 extern "C" int lade_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, float* Cpart,
-                                int32_t M, int32_t N, int32_t K, int32_t n_split, int32_t bn, int32_t mb, int32_t mt, int32_t dtype,
-                                void* stream) {
+                                int32_t M, int32_t N, int32_t K, int32_t n_split, int32_t bn, int32_t mb, int32_t mt, int32_t nt,
+                                int32_t dtype, void* stream) {
     LADE_REQUIRE(A && W && M > 0 && N > 0 && K > 0 && n_split >= 1, LADE_E_ARG, "lade_gemm_skinny: M=%d N=%d K=%d split=%d", M, N, K, n_split);
     LADE_REQUIRE(K % G_BK == 0 && lda % 8 == 0 && ldw % 8 == 0 && N % 8 == 0, LADE_E_ARG,
                  "lade_gemm_skinny: K=%d must be a multiple of %d, strides / N multiples of 8", K, G_BK);
@@ -242,51 +243,36 @@ extern "C" int lade_gemm_skinny(const void* A, int64_t lda, const void* W, int64
     LADE_REQUIRE(dtype == LADE_BF16 || dtype == LADE_F16, LADE_E_DTYPE, "lade_gemm_skinny: dtype=%d", dtype);
     if (mb == 0) mb = M <= 32 ? 1 : (M <= 64 ? 2 : (M <= 96 ? 3 : 4));
     if (mt == 0) mt = 1;
-    LADE_REQUIRE(mb >= 1 && mb <= 4 && (mt == 1 || mt == 2 || mt == 4) && mb % mt == 0, LADE_E_ARG, "lade_gemm_skinny: mb=%d mt=%d", mb, mt);
+    LADE_REQUIRE(mb >= 1 && mb <= 4 && mt >= 1 && mt <= 4 && mb % mt == 0, LADE_E_ARG, "lade_gemm_skinny: mb=%d mt=%d", mb, mt);
+    const int mw = mb / mt;
+    const int tiles = bn <= 32 ? 1 : (bn <= 64 ? 2 : (bn <= 128 ? 4 : (bn <= 192 ? 6 : 8)));      // 32-row weight tiles per work-group
+    if (nt == 0) {                                     // default: as many n-groups as waves allow
+        const int ng_max = 8 / mw;
+        nt = 1;
+        while (tiles / nt > ng_max || tiles % nt != 0) ++nt;
+    }
+    LADE_REQUIRE(nt >= 1 && nt <= 4 && tiles % nt == 0, LADE_E_ARG, "lade_gemm_skinny: bn=%d (%d tiles) nt=%d", bn, tiles, nt);
+    const int ng = tiles / nt;
     GemmK g;
     g.A = (const uint16_t*)A; g.W = (const uint16_t*)W; g.C = (uint16_t*)C; g.Cpart = Cpart;
     g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.n_split = n_split;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("LADE_GEMM_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
     hipStream_t st = (hipStream_t)stream;
-    const int nt32 = bn <= 32 ? 1 : (bn <= 64 ? 2 : (bn <= 128 ? 4 : (bn <= 192 ? 6 : 8)));      // 32-row weight tiles per work-group
-    // (MW, MT) families; within one, the weight tiles are spread over as many n-groups as there are waves left
-#define FAM_MW1(TT, MTv)   /* MW = 1: up to 8 n-groups */                                  \
-    switch (nt32) {                                                                         \
-        case 1: return launch_gemm<TT, 1, MTv, 1, 1>(g, st);                               \
-        case 2: return launch_gemm<TT, 1, MTv, 2, 1>(g, st);                               \
-        case 4: return launch_gemm<TT, 1, MTv, 4, 1>(g, st);                               \
-        case 6: return launch_gemm<TT, 1, MTv, 6, 1>(g, st);                               \
-        default: return launch_gemm<TT, 1, MTv, 8, 1>(g, st);                              \
-    }
-#define FAM_MW2(TT, MTv)   /* MW = 2: up to 4 n-groups */                                  \
-    switch (nt32) {                                                                         \
-        case 1: return launch_gemm<TT, 2, MTv, 1, 1>(g, st);                               \
-        case 2: return launch_gemm<TT, 2, MTv, 2, 1>(g, st);                               \
-        case 4: return launch_gemm<TT, 2, MTv, 4, 1>(g, st);                               \
-        case 6: return launch_gemm<TT, 2, MTv, 3, 2>(g, st);                               \
-        default: return launch_gemm<TT, 2, MTv, 4, 2>(g, st);                              \
-    }
-#define FAM_MW34(TT, MWv)  /* MW = 3 | 4, MT = 1: 2 n-groups */                            \
-    switch (nt32) {                                                                         \
-        case 1: return launch_gemm<TT, MWv, 1, 1, 1>(g, st);                               \
-        case 2: return launch_gemm<TT, MWv, 1, 2, 1>(g, st);                               \
-        case 4: return launch_gemm<TT, MWv, 1, 2, 2>(g, st);                               \
-        case 6: return launch_gemm<TT, MWv, 1, 2, 3>(g, st);                               \
-        default: return launch_gemm<TT, MWv, 1, 2, 4>(g, st);                              \
-    }
-#define GO(TT)                                                                              \
-    if (mb == 1) { FAM_MW1(TT, 1) }                                                         \
-    if (mb == 2 && mt == 1) { FAM_MW2(TT, 1) }                                              \
-    if (mb == 2 && mt == 2) { FAM_MW1(TT, 2) }                                              \
-    if (mb == 3) { FAM_MW34(TT, 3) }                                                        \
-    if (mb == 4 && mt == 1) { FAM_MW34(TT, 4) }                                             \
-    if (mb == 4 && mt == 2) { FAM_MW2(TT, 2) }                                              \
-    { FAM_MW1(TT, 4) }
+#define SHAPE(TT, MWv, MTv, NGv, NTv) if (mw == MWv && mt == MTv && ng == NGv && nt == NTv) return launch_gemm<TT, MWv, MTv, NGv, NTv>(g, st);
+#define GO(TT)                                                                                                               \
+    /* 32 rows */  SHAPE(TT,1,1,1,1) SHAPE(TT,1,1,2,1) SHAPE(TT,1,1,4,1) SHAPE(TT,1,1,8,1) SHAPE(TT,1,1,2,2) SHAPE(TT,1,1,4,2)  \
+    /* 64 rows */  SHAPE(TT,2,1,1,1) SHAPE(TT,2,1,2,1) SHAPE(TT,2,1,4,1) SHAPE(TT,2,1,3,2) SHAPE(TT,2,1,4,2)                    \
+                   SHAPE(TT,1,2,2,1) SHAPE(TT,1,2,4,1) SHAPE(TT,1,2,6,1) SHAPE(TT,1,2,8,1) SHAPE(TT,1,2,2,2) SHAPE(TT,1,2,3,2)  \
+                   SHAPE(TT,1,2,4,2) SHAPE(TT,1,2,2,3) SHAPE(TT,1,2,2,4)                                                       \
+    /* 96 rows */  SHAPE(TT,3,1,1,1) SHAPE(TT,3,1,2,1) SHAPE(TT,3,1,2,2) SHAPE(TT,3,1,2,3) SHAPE(TT,3,1,2,4)                    \
+                   SHAPE(TT,1,3,4,1) SHAPE(TT,1,3,6,1) SHAPE(TT,1,3,8,1) SHAPE(TT,1,3,3,2) SHAPE(TT,1,3,4,2)                    \
+    /* 128 rows */ SHAPE(TT,4,1,1,1) SHAPE(TT,4,1,2,1) SHAPE(TT,4,1,2,2) SHAPE(TT,4,1,2,3) SHAPE(TT,4,1,2,4)                    \
+                   SHAPE(TT,2,2,2,1) SHAPE(TT,2,2,4,1) SHAPE(TT,2,2,3,2) SHAPE(TT,2,2,4,2) SHAPE(TT,2,2,2,2)                    \
+                   SHAPE(TT,1,4,4,1) SHAPE(TT,1,4,6,1) SHAPE(TT,1,4,8,1) SHAPE(TT,1,4,3,2) SHAPE(TT,1,4,4,2) SHAPE(TT,1,4,2,2)
     if (dtype == LADE_BF16) { GO(BF16) } else { GO(F16) }
 #undef GO
-#undef FAM_MW1
-#undef FAM_MW2
-#undef FAM_MW34
+#undef SHAPE
+    LADE_REQUIRE(false, LADE_E_ARG, "lade_gemm_skinny: no kernel for mb=%d mt=%d bn=%d nt=%d (wave grid %d x %d)", mb, mt, bn, nt, mw, ng);
 }
 
 extern "C" int lade_splitk_reduce(const float* part, void* C, int64_t ldc, int32_t M, int32_t N, int32_t n_split, int32_t dtype, void* stream) {

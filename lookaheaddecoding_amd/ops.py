@@ -198,7 +198,7 @@ def softmax_rows(logits: torch.Tensor, temperature: float = 1.0) -> torch.Tensor
 
 
 def gemm_skinny(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, n_split: int = 1, bn: int = 128,
-                part: Optional[torch.Tensor] = None, mb: int = 0, mt: int = 0) -> torch.Tensor:
+                part: Optional[torch.Tensor] = None, mb: int = 0, mt: int = 0, nt: int = 0) -> torch.Tensor:
     """out[M,N] = a[M,K] @ w[N,K]^T on the hand-written weight-streaming kernel (bf16 / f16)."""
     M, K = a.shape
     N = w.shape[0]
@@ -207,18 +207,18 @@ def gemm_skinny(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = 
         out = torch.empty(M, N, dtype=a.dtype, device=a.device)
     if n_split > 1 and part is None:
         part = torch.empty(n_split, M, N, dtype=torch.float32, device=a.device)
-    call("lade_gemm_skinny", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(out), out.stride(0), ptr(part), M, N, K, n_split, bn, mb, mt, dtype_code(a))
+    call("lade_gemm_skinny", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(out), out.stride(0), ptr(part), M, N, K, n_split, bn, mb, mt, nt, dtype_code(a))
     if n_split > 1:
         call("lade_splitk_reduce", ptr(part), ptr(out), out.stride(0), M, N, n_split, dtype_code(a))
     return out
 
 
-def gemm_parts(a: torch.Tensor, w: torch.Tensor, part: torch.Tensor, n_split: int, bn: int, mb: int, mt: int = 0) -> None:
+def gemm_parts(a: torch.Tensor, w: torch.Tensor, part: torch.Tensor, n_split: int, bn: int, mb: int, mt: int = 0, nt: int = 0) -> None:
     """split-K GEMM that leaves its result as n_split fp32 partials in `part` ([n_split][M][N], contiguous) for a
     `*_parts` consumer kernel - no reduce pass."""
     M, K = a.shape
     N = w.shape[0]
-    call("lade_gemm_skinny", ptr(a), a.stride(0), ptr(w), w.stride(0), None, 0, ptr(part), M, N, K, n_split, bn, mb, mt, dtype_code(a))
+    call("lade_gemm_skinny", ptr(a), a.stride(0), ptr(w), w.stride(0), None, 0, ptr(part), M, N, K, n_split, bn, mb, mt, nt, dtype_code(a))
 
 
 def add_rmsnorm_parts(x: torch.Tensor, part: torch.Tensor, n_parts: int, w: torch.Tensor, eps: float, out: torch.Tensor) -> torch.Tensor:

@@ -45,10 +45,13 @@ for M in [int(x) for x in os.environ.get('M', '60,120').split(',')]:
         t_ref = timeit(ref)
         res = []
         want = torch.matmul(a.float(), ws[0].float().t())
-        shapes_ = ([(2, 1, 32), (2, 1, 64), (2, 1, 128), (2, 1, 256), (2, 2, 128), (2, 2, 192), (2, 2, 256)] + ([(1, 1, 64), (1, 1, 128), (1, 1, 256)] if M <= 32 else [])
-                   if M <= 64 else [(4, 1, 64), (4, 1, 128), (4, 1, 192), (4, 1, 256), (4, 2, 128), (4, 2, 192), (4, 2, 256), (4, 4, 128), (4, 4, 192), (4, 4, 256)]
-                   + ([(3, 1, 128), (3, 1, 192)] if M <= 96 else []))
-        for mb, MT, bn in shapes_:
+        # (mb, mt, bn, nt): nt = 0 -> as many n-groups as waves allow
+        shapes_ = ([(2, 1, 64, 0), (2, 1, 128, 0), (2, 1, 256, 0), (2, 2, 128, 0), (2, 2, 192, 0), (2, 2, 256, 0), (2, 2, 128, 2), (2, 2, 192, 2), (2, 2, 256, 2),
+                    (2, 2, 192, 3), (2, 2, 256, 4)] + ([(1, 1, 64, 0), (1, 1, 128, 0), (1, 1, 256, 0), (1, 1, 128, 2), (1, 1, 256, 2)] if M <= 32 else [])
+                   if M <= 64 else [(4, 1, 128, 0), (4, 1, 192, 0), (4, 1, 256, 0), (4, 2, 128, 0), (4, 2, 192, 0), (4, 2, 256, 0), (4, 2, 128, 2), (4, 4, 128, 0),
+                                    (4, 4, 192, 0), (4, 4, 256, 0), (4, 4, 192, 2), (4, 4, 256, 2), (4, 4, 128, 2)]
+                   + ([(3, 1, 128, 0), (3, 1, 192, 0), (3, 3, 128, 0), (3, 3, 192, 0), (3, 3, 256, 0), (3, 3, 192, 2), (3, 3, 256, 2)] if M <= 96 else []))
+        for mb, MT, bn, NTW in shapes_:
             for S in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16):
                 part = torch.empty(S, M, N, dtype=torch.float32, device="cuda") if S > 1 else None
 
@@ -56,17 +59,17 @@ for M in [int(x) for x in os.environ.get('M', '60,120').split(',')]:
                     i[0] = (i[0] + 1) % len(ws)
                     if NO_REDUCE and S > 1:
                         from lookaheaddecoding_amd.cabi import call, ptr, dtype_code
-                        call('lade_gemm_skinny', ptr(a), a.stride(0), ptr(ws[i[0]]), ws[i[0]].stride(0), ptr(out), out.stride(0), ptr(part), M, N, K, S, bn, mb, MT, dtype_code(a))
+                        call('lade_gemm_skinny', ptr(a), a.stride(0), ptr(ws[i[0]]), ws[i[0]].stride(0), ptr(out), out.stride(0), ptr(part), M, N, K, S, bn, mb, MT, NTW, dtype_code(a))
                     else:
-                        ops.gemm_skinny(a, ws[i[0]], out=out, n_split=S, bn=bn, part=part, mb=mb, mt=MT)
+                        ops.gemm_skinny(a, ws[i[0]], out=out, n_split=S, bn=bn, part=part, mb=mb, mt=MT, nt=NTW)
 
                 try:
-                    got = ops.gemm_skinny(a, ws[0], n_split=S, bn=bn, mb=mb, mt=MT).float()
+                    got = ops.gemm_skinny(a, ws[0], n_split=S, bn=bn, mb=mb, mt=MT, nt=NTW).float()
                     err = (got - want).abs().max().item()
                     t = timeit(mine)
-                    res.append((t, f"{mb}.{MT}x{bn}", S, err))
+                    res.append((t, f"{mb}.{MT}x{bn}.{NTW}", S, err))
                 except Exception as ex:
-                    res.append((float("inf"), f"{mb}.{MT}x{bn}", S, 0.0))
+                    res.append((float("inf"), f"{mb}.{MT}x{bn}.{NTW}", S, 0.0))
         res.sort(key=lambda x: x[0])
         assert max(r[3] for r in res) < 0.2, max(res, key=lambda r: r[3])
         mb = N * K * 2 / 1e6
