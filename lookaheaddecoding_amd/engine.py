@@ -122,9 +122,10 @@ class StepEngine:
         forced = int(os.environ.get("LADE_ATTN_SPLITS", "0"))        # experiments only
         if forced > 0:
             return min(forced, self.max_splits, max(1, (S_tot + 63) // 64))
-        # always the split + merge form: the hipGraph steps are captured with it, and an eager step of the same
-        # sequence must round the same way (16-bit partials) for the two modes to produce the same token stream
-        return min(ops.choose_splits(self.H, self.H // self.Hkv, T, S_tot, self.n_cu, allow_single=False), self.max_splits)
+        # always the split + merge form, and never fewer splits than a 1024-key cache would get: the hipGraph steps are
+        # captured with exactly that rule, and an eager step of the same (short) sequence must round the same way
+        # (16-bit partials) for the two modes to produce the same token stream
+        return min(ops.choose_splits(self.H, self.H // self.Hkv, T, max(S_tot, 1024), self.n_cu, allow_single=False), self.max_splits)
 
     # ---- GEMM selection ---------------------------------------------------------------------------
     def _tune(self, name: str, M: int):

@@ -53,7 +53,9 @@ def choose_splits(H: int, n_rep: int, T: int, S_tot: int, n_cu: int = 256, allow
     tiles = max(1, (S_tot + 63) // 64)
     if tiles <= 5 and allow_single:               # <= 320 keys: one work-group per head beats a second (merge) launch
         return 1                                  # (tools/attn_bench.py: 7.3-9.8 us vs 10.0-10.3 us at P = 64..256, T = 60)
-    want = max(1, min(n_cu // max(blocks, 1), tiles, 32))
+    # streaming time per work-group falls as tiles/splits, the merge (and the partial round trip) grows with splits:
+    # the measured optimum inside decode steps follows sqrt(tiles) - 5 splits at 18 tiles, 6 at 34, 8 at 65
+    want = max(1, min(n_cu // max(blocks, 1), math.isqrt(max(tiles - 1, 0)) + 1, tiles, 32))
     tps = (tiles + want - 1) // want              # tiles per split
     return (tiles + tps - 1) // tps               # drop the splits that would be empty
 
