@@ -201,6 +201,8 @@ class LookaheadDecoder:
             self._capture_graphs()
         gcap = min(b for b in self._graphs if b >= self.g)
         T = self._graph_T[gcap]
+        if abs(e.n_splits_for(T, self.P + T) - self._graph_splits[gcap]) >= 2:      # the cache outgrew the captured KV split count
+            self._capture_graphs()
         if self.P + T > e.S_max:
             raise cabi.LadeHipError(f"KV cache exhausted: P={self.P} + T={T} > S_max={e.S_max}")
         P_before = self.P

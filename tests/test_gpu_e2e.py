@@ -148,6 +148,23 @@ def test_long_generation_equals_plain_greedy_and_the_oracle_fp32():
     assert [t["max_hit"] for t in outs[0].trace[:n_ref - 1]] == [t.max_hit for t in ref.trace[:n_ref - 1]]
 
 
+def test_graph_recapture_when_the_cache_outgrows_its_split_count():
+    """bf16, 2600 new tokens in graph mode: the KV split count of the captured attention follows the cache length
+    (re-capture), the run completes, and its head equals an eager run (identical rounding while the split counts agree)."""
+    from lookaheaddecoding_amd.decoding import LookaheadDecoder
+    cfg, w, eng = make_engine("tiny-d128", torch.bfloat16, 2, 0.05, max_seq=4096)
+    prompt = [1, 5, 9, 17, 33, 5, 9, 17, 44, 5, 9]
+    dec = LookaheadDecoder(eng, 7, 4, 7, use_graph=True)
+    captures = []
+    orig = dec._capture_graphs
+    dec._capture_graphs = lambda *a, **k: (captures.append(dec.P), orig(*a, **k))[1]
+    out = dec.greedy(prompt, len(prompt) + 2600, rng=random.Random(5))
+    assert out.generated == 2600 and all(0 <= t < cfg["vocab"] for t in out.tokens)
+    assert len(captures) >= 2 and captures[-1] > 1024, captures
+    eager = LookaheadDecoder(eng, 7, 4, 7).greedy(prompt, len(prompt) + 300, rng=random.Random(5))
+    assert eager.tokens == out.tokens[:len(eager.tokens)]
+
+
 def test_sampling_fp32_identical_tokens_vs_reference():
     """jacobi_sample_multilevel parity: same python/torch RNG order, probabilities from the HIP step in fp32 ->
     the reference's sampled token ids and step counts (temperature / top-k / top-p runs)."""
