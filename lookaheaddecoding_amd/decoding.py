@@ -347,6 +347,8 @@ class LookaheadDecoder:
                 phase, n_input, n_inp = 2, 1, W
                 gcap = min(b for b in self._graphs if b >= g)
                 T, cand_rows = self._graph_T[gcap], gcap * gs
+                if abs(e.n_splits_for(T, P + T) - self._graph_splits[gcap]) >= 2:
+                    self._capture_graphs(forward_only=True)
                 if P + T > e.S_max:
                     raise cabi.LadeHipError(f"KV cache exhausted: P={P} + T={T} > S_max={e.S_max}")
                 mask = StepMask.from_levels(1, self._level_sizes(N - 2), cand_rows, gs, P)
