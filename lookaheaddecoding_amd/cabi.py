@@ -14,7 +14,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblade_hip.so")
+LIB_PATH = os.environ.get("LADE_HIP_LIB") or os.path.join(_HERE, "liblade_hip.so")     # env override: kernel experiments
 
 LADE_BF16, LADE_F16, LADE_F32 = 0, 1, 2
 DTYPE_CODE = {torch.bfloat16: LADE_BF16, torch.float16: LADE_F16, torch.float32: LADE_F32}

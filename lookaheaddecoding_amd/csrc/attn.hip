@@ -160,7 +160,10 @@ template <> struct Mfma<F16> {
     }
 };
 
-constexpr int NSTAGE = 3;              // LDS ring depth: a work-group's first 3 tiles are requested at once
+#ifndef LADE_ATTN_NSTAGE
+#define LADE_ATTN_NSTAGE 3
+#endif
+constexpr int NSTAGE = LADE_ATTN_NSTAGE;   // LDS ring depth: a work-group's first NSTAGE tiles are requested at once
 constexpr float RESCALE_THR = 8.0f;    // log2 units: the running max is only raised when it grows by more
 constexpr int NTHREADS = 512;          // 8 waves: 4 row groups x 2 key halves, two waves per SIMD
 
@@ -301,7 +304,8 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(AttnK a) {
         // wait for tile i (and, the first time, the older Q pieces): the pieces of the (up to 2) younger
         // tiles stay in flight
         const int younger = min(nt, i + NSTAGE) - (i + 1);
-        if (younger >= 2) wait_vm<2 * PIECES>();
+        if (NSTAGE > 3 && younger >= 3) wait_vm<3 * PIECES>();
+        else if (younger >= 2) wait_vm<2 * PIECES>();
         else if (younger == 1) wait_vm<PIECES>();
         else wait_vm<0>();
         wg_barrier();
