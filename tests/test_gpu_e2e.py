@@ -148,6 +148,26 @@ def test_long_generation_equals_plain_greedy_and_the_oracle_fp32():
     assert [t["max_hit"] for t in outs[0].trace[:n_ref - 1]] == [t.max_hit for t in ref.trace[:n_ref - 1]]
 
 
+def test_reference_default_configuration_w60_n8_g60():
+    """config_lade never called: the reference falls back to WINDOW_SIZE=60, LEVEL=8, GUESS_SET_SIZE=60
+    (lade/decoding.py:854-857) - steps of up to 847 tokens.  Tokens, steps and acceptance pattern vs the oracle (fp32), and
+    the bf16 MFMA path against plain greedy on the same kernels."""
+    from lookaheaddecoding_amd.decoding import LookaheadDecoder
+    prompt = [1, 5, 9, 17, 33, 5, 9, 17, 44, 5, 9, 2, 5, 9, 17]
+    cfg, w, eng = make_engine("tiny-d64", torch.float32, 1, 0.05, max_seq=2048)
+    eng = type(eng)(cfg, w, dtype=torch.float32, max_seq=2048, max_T=896)
+    model = O.OracleLlama(cfg, {k: torch.as_tensor(v) for k, v in w.items()})
+    ref = O.lookahead_greedy(model, prompt, 60, 8, 60, len(prompt) + 48, random.Random(2), keep_trace=True)
+    for use_graph in (False, True):
+        out = LookaheadDecoder(eng, 60, 8, 60, use_graph=use_graph).greedy(prompt, len(prompt) + 48, rng=random.Random(2), keep_trace=True)
+        assert out.tokens == ref.tokens and out.steps == ref.steps, use_graph
+        assert [t["max_hit"] for t in out.trace] == [t.max_hit for t in ref.trace]
+    cfg, w, eng16 = make_engine("tiny-d128", torch.bfloat16, 2, 0.05, max_seq=2048)
+    eng16 = type(eng16)(cfg, w, dtype=torch.bfloat16, max_seq=2048, max_T=896)
+    out = LookaheadDecoder(eng16, 60, 8, 60).greedy(prompt, len(prompt) + 40, rng=random.Random(2))
+    assert out.tokens == eng16.plain_greedy(prompt, len(prompt) + 40)
+
+
 def test_graph_recapture_when_the_cache_outgrows_its_split_count():
     """bf16, 2600 new tokens in graph mode: the KV split count of the captured attention follows the cache length
     (re-capture), the run completes, and its head equals an eager run (identical rounding while the split counts agree)."""
