@@ -122,6 +122,7 @@ def _layouts():
         ("lp_refeed", 4, [3, 2, 2, 2], 8, 4, False),                # level_offset 3 (re-fed hits)
         ("prefill", 37, [20], 0, 4, True),
         ("c4_big", 1, [19] + [20] * 5, 120, 6, False),              # config 4: T = 240
+        ("ref_default", 1, [59] + [60] * 6, 420, 7, False),         # the reference's defaults W=60 N=8 G=60: T = 840
     ]
 
 
