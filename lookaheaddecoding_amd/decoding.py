@@ -277,17 +277,21 @@ class LookaheadDecoder:
 
     @torch.no_grad()
     def greedy(self, prompt: Sequence[int], max_length: int, eos_token_id: Optional[int] = None,
-               rng: Optional[random.Random] = None, keep_trace: bool = False) -> GenOut:
-        """`jacobi_greedy_search_multilevel` (lade/decoding.py:697-1259), single GPU or lookahead parallel."""
+               rng: Optional[random.Random] = None, keep_trace: bool = False, on_step=None) -> GenOut:
+        """`jacobi_greedy_search_multilevel` (lade/decoding.py:697-1259), single GPU or lookahead parallel.
+        on_step(accepted_tokens): called after every step with the tokens it accepted (chat printing / HF streamers,
+        lade/decoding.py:1179-1200)."""
         if self.lp is not None and self.lp.R > 1:
             from .parallel import greedy_lp
-            return greedy_lp(self, prompt, max_length, eos_token_id, rng, keep_trace)
+            return greedy_lp(self, prompt, max_length, eos_token_id, rng, keep_trace, on_step=on_step)
         self.start(prompt, eos_token_id, rng)
         trace: List[dict] = []
         while True:
             info = self.step()
             if keep_trace:
                 trace.append(info)
+            if on_step is not None:
+                on_step(info["accepted"][:max(0, max_length - (len(self.tokens) - len(info["accepted"])))])
             if self.finished_by_eos or len(self.tokens) >= max_length:      # stopping criteria (:1204-1219)
                 break
         generated = min(len(self.tokens), max_length) - len(self.prompt)
@@ -300,7 +304,8 @@ class LookaheadDecoder:
     # ---- sampling ------------------------------------------------------------------------------------
     @torch.no_grad()
     def sample(self, prompt: Sequence[int], max_length: int, warp=None, eos_token_id: Optional[int] = None,
-               rng: Optional[random.Random] = None, torch_gen: Optional[torch.Generator] = None, keep_trace: bool = False) -> GenOut:
+               rng: Optional[random.Random] = None, torch_gen: Optional[torch.Generator] = None, keep_trace: bool = False,
+               on_step=None) -> GenOut:
         """`jacobi_sample_multilevel` (lade/decoding.py:137-692), single GPU (the reference has no LP here).
 
         The model step, input assembly, pool and window stay on the GPU; what runs on the host is exactly what
@@ -399,6 +404,8 @@ class LookaheadDecoder:
             self.steps += 1
             n_accept, eos_hit, self.g, self.P = rec[1], rec[2], rec[3], rec[4]
             accepted = hits[:n_accept]
+            if on_step is not None:
+                on_step(accepted[:max(0, max_length - len(self.tokens))])
             self.tokens += accepted
             all_old_tokens += accepted
             if phase != 2:

@@ -232,19 +232,34 @@ def _run(self, input_ids, do_sample, warp, stopping_criteria, eos_token_id, gene
         dec = LookaheadDecoder(eng, W, N, G, pool_from_prompt=key[3], lp=lp, use_graph=bool(int(os.environ.get("LADE_GRAPH", "1"))) and R == 1)
         dec._key = key
         self._lade_decoder = dec
+    # per-step output like the reference: decoded text printed incrementally under CHAT=1 (lade/decoding.py:1179-1195),
+    # accepted tokens handed to the HF streamer as they are accepted (:1199-1200)
+    rank0 = CONFIG_MAP.get("LOCAL_RANK", 0) == 0
+    tok = getattr(self, "tokenizer", None) if (chat and rank0) else None
+    shown = {"ids": [], "n": 0}
+
+    def on_step(accepted):
+        if not accepted:
+            return
+        if streamer is not None:
+            streamer.put(torch.tensor(accepted, dtype=input_ids.dtype))
+        if tok is not None:
+            shown["ids"] += accepted
+            text = tok.decode(shown["ids"], skip_special_tokens=True, spaces_between_special_tokens=False, clean_up_tokenization_spaces=True)
+            print(text[shown["n"]:], flush=True, end="")
+            shown["n"] = len(text)
+
+    cb = on_step if (streamer is not None or tok is not None) else None
     if do_sample:
-        out = dec.sample(prompt, max_length, warp=warp, eos_token_id=eos_token_id, rng=random)
+        out = dec.sample(prompt, max_length, warp=warp, eos_token_id=eos_token_id, rng=random, on_step=cb)
     else:
-        out = dec.greedy(prompt, max_length, eos_token_id=eos_token_id, rng=random)
-    if CONFIG_MAP.get("DEBUG", 0) and CONFIG_MAP.get("LOCAL_RANK", 0) == 0:
+        out = dec.greedy(prompt, max_length, eos_token_id=eos_token_id, rng=random, on_step=cb)
+    if CONFIG_MAP.get("DEBUG", 0) and rank0:
         print("\n==========================ACCELERATION===SUMMARY======================================")
         print("Generated tokens: ", out.generated, "Total steps: ", out.steps, " Compression ratio: ", round(out.generated / max(out.steps, 1), 2))
         print("======================================================================================", end="")
-    if chat and getattr(self, "tokenizer", None) is not None and CONFIG_MAP.get("LOCAL_RANK", 0) == 0:
-        print(self.tokenizer.decode(out.tokens[len(prompt):], skip_special_tokens=True), flush=True, end="")
     res = torch.tensor([out.tokens], dtype=input_ids.dtype, device=input_ids.device)
     if streamer is not None:
-        streamer.put(res[:, len(prompt):].cpu())
         streamer.end()
     return res
 

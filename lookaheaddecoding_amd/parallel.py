@@ -210,7 +210,7 @@ class LPRunner:
 
 
 def greedy_lp(dec, prompt: Sequence[int], max_length: int, eos_token_id: Optional[int] = None,
-              rng: Optional[random.Random] = None, keep_trace: bool = False, backend=None, all_gather=None):
+              rng: Optional[random.Random] = None, keep_trace: bool = False, backend=None, all_gather=None, on_step=None):
     """Greedy lookahead decoding under lookahead parallelism (jacobi_greedy_search_multilevel with
     DIST_WORKERS > 1, lade/decoding.py:697-1259)."""
     from .decoding import GenOut
@@ -221,6 +221,8 @@ def greedy_lp(dec, prompt: Sequence[int], max_length: int, eos_token_id: Optiona
         info = run.step()
         if keep_trace:
             trace.append(info)
+        if on_step is not None:
+            on_step(info["accepted"][:max(0, max_length - (len(run.tokens) - len(info["accepted"])))])
         if run.finished or len(run.tokens) >= max_length:
             break
     generated = min(len(run.tokens), max_length) - len(run.prompt)

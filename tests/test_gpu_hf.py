@@ -115,3 +115,38 @@ def test_jforward_multilevel_boundary_matches_oracle_step(hf_model):
     ref = O.model_step(om, cache, ins, pos, sh, guess[:gs], N - 2, gs)
     out = call(ins, pos, sh, guess[:gs], N - 2, pkv)
     check(out, ref, "lp shard")
+
+
+def test_streamer_receives_tokens_step_by_step(hf_model, monkeypatch):
+    """HF streamers get the accepted tokens of every step as they are accepted (lade/decoding.py:1199-1200), greedy and sampling."""
+    import lade
+    from transformers import GenerationMixin
+    orig = GenerationMixin._sample
+
+    class Collect:
+        def __init__(self):
+            self.chunks, self.ended = [], False
+
+        def put(self, value):
+            self.chunks.append(value.reshape(-1).tolist())
+
+        def end(self):
+            self.ended = True
+
+    prompt = torch.tensor([[1, 5, 9, 17, 33, 5, 9, 17, 44, 5, 9]], device="cuda")
+    try:
+        lade.augment_all()
+        lade.config_lade(LEVEL=4, WINDOW_SIZE=5, GUESS_SET_SIZE=5, DEBUG=0)
+        monkeypatch.setenv("USE_LADE", "1")
+        for kw in (dict(do_sample=False), dict(do_sample=True, temperature=0.7, top_k=0, top_p=1.0)):
+            st = Collect()
+            random.seed(3)
+            out = hf_model.generate(prompt, attention_mask=torch.ones_like(prompt), max_new_tokens=30, streamer=st, **kw)
+            assert st.ended and st.chunks[0] == prompt[0].tolist()                 # HF hands the prompt over first
+            streamed = [t for c in st.chunks[1:] for t in c]
+            assert streamed == out[0, prompt.shape[1]:].tolist()
+            assert len(st.chunks) > 3                                               # several steps, not one final dump
+    finally:
+        GenerationMixin._sample = orig
+        lade.decoding.FUNC_MAP.pop("_sample", None)
+        lade.decoding.CONFIG_MAP.clear()
