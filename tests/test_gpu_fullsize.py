@@ -135,3 +135,35 @@ def test_skinny_gemm_vs_fp32_reference():
                 continue
             out = ops.gemm_skinny(a, w, n_split=S, bn=bn, mb=mb, mt=mt, nt=nt).float()
             assert torch.allclose(out, ref, atol=2e-2 * max(1.0, ref.abs().max().item() / 8), rtol=2e-2), (M, N, K, S, bn, mb, mt, nt, (out - ref).abs().max())
+
+
+@pytest.mark.parametrize("shape,layers,W,N,G", [("llama2-7b", 2, 15, 5, 15), ("codellama-13b", 2, 20, 7, 20), ("llama2-70b", 1, 15, 5, 15)])
+def test_fullsize_shapes_end_to_end_on_a_successor_model(shape, layers, W, N, G):
+    """BASELINE shapes (hidden / heads / GQA / vocab at full size, few layers) through the whole step in bf16, graph and
+    eager mode: a model whose greedy continuation is known in closed form (o_proj / down_proj zeroed, lm_head = shifted
+    embedding -> token t is followed by (t+1) mod C) must be decoded exactly, with every step accepting a full n-gram,
+    and lookahead must equal plain greedy decoding on the same engine."""
+    from lookaheaddecoding_amd.decoding import LookaheadDecoder
+    from lookaheaddecoding_amd.engine import StepEngine
+    from lookaheaddecoding_amd.weights import make_config, random_weights_torch
+    cfg = make_config(shape)
+    cfg["layers"] = layers
+    w = random_weights_torch(cfg, seed=0, dtype=torch.bfloat16, device="cuda")
+    eng = StepEngine(cfg, w, dtype=torch.bfloat16, device="cuda", max_seq=1024, max_T=512)
+    del w
+    C = 256
+    for lw in eng.layers:
+        lw["wo"].zero_()
+        lw["wd"].zero_()
+    head = eng.embed.clone()
+    head[:C] = eng.embed[(torch.arange(C, device="cuda") - 1) % C]
+    eng.lm_head = head
+    prompt = [i % C for i in range(300)]
+    n_new = 96
+    want = [(prompt[-1] + 1 + i) % C for i in range(n_new)]
+    assert eng.plain_greedy(prompt, len(prompt) + 24)[len(prompt):] == want[:24]
+    for use_graph in (False, True):
+        dec = LookaheadDecoder(eng, W, N, G, pool_from_prompt=True, use_graph=use_graph)
+        out = dec.greedy(prompt, len(prompt) + n_new, rng=random.Random(1))
+        assert out.tokens[len(prompt):] == want, (shape, use_graph)
+        assert out.steps <= n_new // (N - 1) + N, (shape, use_graph, out.steps)      # ~N-1 tokens per step after the window has filled
