@@ -386,6 +386,53 @@ def gen_e2e_sample():
         print("sample", mname, wk, "steps", steps, "gen", gen)
     dump("e2e_sample.json", {"runs": runs})
 
+
+
+def gen_e2e_sample_eos():
+    """Sampling runs that exercise filter_window (EOS replaced in the newest window level, lade/decoding.py:578-580), the EOS
+    stop of the sampling loop (:592-604) and POOL_FROM_PROMPT under sampling (:367-368, :602-603)."""
+    runs = []
+    for (mname, pname, W, N, G, new, seed, wk, pfp, eos_rank) in [("tiny-d16", "rep", 5, 4, 5, 40, 1, dict(temperature=0.8), 0, 0),
+                                                                 ("tiny-d16", "rep", 5, 4, 5, 40, 2, dict(temperature=0.3), 1, 1),
+                                                                 ("tiny-d64", "rep2", 4, 3, 4, 36, 3, dict(temperature=0.5, top_k=20), 1, None)]:
+        cfg, w, model = get_model(mname)
+        prompt = [t % cfg["vocab"] for t in PROMPTS[pname]]
+        warp = LogitsProcessorList()
+        if "temperature" in wk:
+            warp.append(TemperatureLogitsWarper(wk["temperature"]))
+        if "top_k" in wk:
+            warp.append(TopKLogitsWarper(wk["top_k"]))
+
+        def run(eos):
+            D.CONFIG_MAP.clear()
+            D.CONFIG_MAP.update(dict(WINDOW_SIZE=W, LEVEL=N, GUESS_SET_SIZE=G, ALWAYS_FWD_ONE=1, DEBUG=1, POOL_FROM_PROMPT=pfp, USE_FLASH=0, log=[]))
+            rec = Recorder(model)
+            random.seed(seed)
+            torch.manual_seed(seed)
+            ids = torch.tensor([prompt])
+            with torch.no_grad():
+                out = D.jacobi_sample_multilevel(model, ids, logits_processor=LogitsProcessorList(), logits_warper=warp,
+                                                 stopping_criteria=StoppingCriteriaList([MaxLengthCriteria(len(prompt) + new)]),
+                                                 pad_token_id=0, eos_token_id=None if eos is None else [eos], attention_mask=torch.ones_like(ids),
+                                                 use_cache=True, return_dict_in_generate=False, output_attentions=False, output_hidden_states=False,
+                                                 output_scores=False, chat=False)
+            rec.remove()
+            gen, steps, _ = D.CONFIG_MAP["log"][-1]
+            return out[0].tolist(), steps, gen, rec
+
+        eos = None
+        if eos_rank is not None:                     # an EOS id that the free run does produce: the run must stop there
+            base, _, _, _ = run(None)
+            gen_toks = base[len(prompt) + 6:]
+            import collections
+            eos = collections.Counter(gen_toks).most_common(eos_rank + 1)[eos_rank][0]
+        toks, steps, gen, rec = run(eos)
+        runs.append({"model": mname, "model_seed": MODELS[mname]["seed"], "std": MODELS[mname]["std"], "prompt": prompt, "W": W, "N": N, "G": G,
+                     "max_length": len(prompt) + new, "seed": seed, "warp": wk, "pool_from_prompt": pfp, "eos": eos, "tokens": toks, "steps": steps,
+                     "generated": gen, "trace": rec.steps})
+        print("sample-eos", mname, wk, "pfp", pfp, "eos", eos, "steps", steps, "gen", gen, "len", len(toks) - len(prompt))
+    dump("e2e_sample_eos.json", {"runs": runs})
+
 # ------------------------------------------------------------------ lookahead parallel (gloo)
 
 
@@ -441,7 +488,7 @@ def gen_e2e_lp():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["pool", "mask", "greedy", "sample", "lp", "unlimited"]
+    what = sys.argv[1:] or ["pool", "mask", "greedy", "sample", "lp", "unlimited", "sample_eos"]
     torch.set_num_threads(4)
     if "pool" in what:
         gen_pool()
@@ -455,3 +502,5 @@ if __name__ == "__main__":
         gen_e2e_lp()
     if "unlimited" in what:
         gen_e2e_unlimited()
+    if "sample_eos" in what:
+        gen_e2e_sample_eos()

@@ -202,6 +202,21 @@ def test_sampling_fp32_identical_tokens_vs_reference():
             assert out.steps == run["steps"]
 
 
+def test_sampling_with_eos_and_pool_from_prompt_vs_reference():
+    """EOS replacement in the newest window level (filter_window), the EOS stop and POOL_FROM_PROMPT in the sampling loop."""
+    from lookaheaddecoding_amd.decoding import LookaheadDecoder
+    from lookaheaddecoding_amd.sampling import make_warper
+    for run in load("e2e_sample_eos.json")["runs"]:
+        cfg, w, eng = make_engine(run, torch.float32)
+        for use_graph in (False, True):
+            dec = LookaheadDecoder(eng, run["W"], run["N"], run["G"], pool_from_prompt=bool(run["pool_from_prompt"]), use_graph=use_graph)
+            torch.manual_seed(run["seed"])
+            out = dec.sample(run["prompt"], run["max_length"], warp=make_warper(**run["warp"]), eos_token_id=run["eos"],
+                             rng=random.Random(run["seed"]), torch_gen=torch.default_generator)
+            assert out.tokens == run["tokens"], (run["warp"], run["eos"], use_graph)
+            assert out.steps == run["steps"]
+
+
 def test_sampling_logits_within_tolerance_bf16():
     """north_star: 'sampling logits match within a stated fp tolerance' - bf16 step logits vs the fp32 oracle on
     the same (bf16-rounded) weights, steady step with candidates: atol 6e-2 on logits of magnitude ~1."""

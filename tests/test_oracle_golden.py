@@ -157,6 +157,20 @@ def test_sampling_e2e_matches_reference():
             assert mine.positions == ref["positions"]
 
 
+def test_sampling_with_eos_and_pool_from_prompt_matches_reference():
+    """filter_window on the newest level, the EOS stop and POOL_FROM_PROMPT inside the sampling loop (lade/decoding.py:578-604)."""
+    d = load("e2e_sample_eos.json")
+    for run in d["runs"]:
+        model = oracle_model(run)
+        torch.manual_seed(run["seed"])
+        res = O.lookahead_sample(model, run["prompt"], run["W"], run["N"], run["G"], run["max_length"], random.Random(run["seed"]),
+                                 torch.default_generator, eos_token_id=run["eos"], pool_from_prompt=bool(run["pool_from_prompt"]), **run["warp"])
+        assert res.tokens == run["tokens"], (run["warp"], run["eos"])
+        assert res.steps == run["steps"]
+        for mine, ref in zip(res.trace, run["trace"]):
+            assert mine.ids == ref["ids"] and mine.positions == ref["positions"]
+
+
 def test_attention_layer_matches_reference_capture():
     """RoPE + dense attention of the oracle against tensors captured inside the reference's own
     LlamaAttention.forward (q/k/v projections, post-step K/V cache, o_proj input)."""
