@@ -436,7 +436,7 @@ def gen_e2e_sample_eos():
 # ------------------------------------------------------------------ lookahead parallel (gloo)
 
 
-def _lp_worker(rank, R, port, mname, prompt, W, N, G, max_length, seed, q, pfp=0):
+def _lp_worker(rank, R, port, mname, prompt, W, N, G, max_length, seed, q, pfp=0, eos=None):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -451,7 +451,7 @@ def _lp_worker(rank, R, port, mname, prompt, W, N, G, max_length, seed, q, pfp=0
     ids = torch.tensor([prompt])
     with torch.no_grad():
         out = D.jacobi_greedy_search_multilevel(model, ids, logits_processor=[], stopping_criteria=StoppingCriteriaList([MaxLengthCriteria(max_length)]),
-                                                pad_token_id=0, eos_token_id=None, attention_mask=torch.ones_like(ids), use_cache=True,
+                                                pad_token_id=0, eos_token_id=None if eos is None else [eos], attention_mask=torch.ones_like(ids), use_cache=True,
                                                 return_dict_in_generate=False, output_attentions=False, output_hidden_states=False,
                                                 output_scores=False, chat=False)
     steps = len(rec.steps)
@@ -464,24 +464,30 @@ def gen_e2e_lp():
     import torch.multiprocessing as mp
     runs = []
     port = 29611
+    eos_of = {}
     for (mname, pname, W, N, G, new, seed, R, pfp) in [("tiny-d16", "rep", 5, 4, 5, 48, 1, 2, 0), ("tiny-d16", "rep", 5, 4, 5, 48, 1, 3, 0),
                                                        ("tiny-d64", "rep2", 7, 5, 7, 40, 1, 2, 0), ("tiny-d64", "rep", 5, 3, 3, 40, 2, 4, 0),
                                                        ("tiny-d16", "rep", 5, 4, 5, 48, 3, 2, 1), ("tiny-d64", "rep2", 6, 4, 4, 40, 2, 3, 1),
-                                                       ("tiny-d64", "rep", 15, 5, 15, 40, 1, 8, 0)]:   # BASELINE config 5's W/N/G over 8 ranks
+                                                       ("tiny-d64", "rep", 15, 5, 15, 40, 1, 8, 0),     # BASELINE config 5's W/N/G over 8 ranks
+                                                       ("tiny-d16", "rep", 5, 4, 5, 48, 1, 2, "eos")]:  # the first run again, stopping at an EOS it generates
         cfg = make_config(mname)
         prompt = [t % cfg["vocab"] for t in PROMPTS[pname]]
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
         port += 1
-        procs = [ctx.Process(target=_lp_worker, args=(r, R, port, mname, prompt, W, N, G, len(prompt) + new, seed, q, pfp)) for r in range(R)]
+        eos = None
+        if pfp == "eos":
+            pfp, eos = 0, eos_of[(mname, pname, W, N, G, seed)][len(prompt) + 20]
+        procs = [ctx.Process(target=_lp_worker, args=(r, R, port, mname, prompt, W, N, G, len(prompt) + new, seed, q, pfp, eos)) for r in range(R)]
         for p in procs:
             p.start()
         res = sorted([q.get(timeout=600) for _ in range(R)])
         for p in procs:
             p.join()
         assert all(r[1] == res[0][1] for r in res)
+        eos_of.setdefault((mname, pname, W, N, G, seed), res[0][1])
         runs.append({"model": mname, "model_seed": MODELS[mname]["seed"], "std": MODELS[mname]["std"], "prompt": prompt, "W": W, "N": N, "G": G,
-                     "max_length": len(prompt) + new, "seed": seed, "R": R, "pool_from_prompt": pfp, "tokens": res[0][1], "steps": res[0][2],
+                     "max_length": len(prompt) + new, "seed": seed, "R": R, "pool_from_prompt": pfp, "eos": eos, "tokens": res[0][1], "steps": res[0][2],
                      "rank_traces": [r[3] for r in res]})
         print("LP", mname, "R", R, "pool_from_prompt", pfp, "steps", res[0][2])
     dump("e2e_lp.json", {"runs": runs})

@@ -79,11 +79,11 @@ def _run_rank(rank, R, run, ex, results, errors):
 
 
 def _greedy_lp_patched(parallel, dec, run, be, ex, rank):
-    return parallel.greedy_lp(dec, run["prompt"], run["max_length"], rng=random.Random(run["seed"] + 1000 * rank), backend=be, keep_trace=True,
+    return parallel.greedy_lp(dec, run["prompt"], run["max_length"], eos_token_id=run.get("eos"), rng=random.Random(run["seed"] + 1000 * rank), backend=be, keep_trace=True,
                               all_gather=lambda out, inp: ex.all_gather(rank, out, inp))
 
 
-@pytest.mark.parametrize("idx", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("idx", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_lp_hip_kernels_match_reference_gloo_runs(idx):
     with open(os.path.join(GOLDEN, "e2e_lp.json")) as f:
         run = json.load(f)["runs"][idx]

@@ -55,13 +55,13 @@ def _worker(rank, R, port, run, q):
         return r
 
     be.local_step = rec_step
-    out = greedy_lp(d, run["prompt"], run["max_length"], rng=random.Random(run["seed"] + 1000 * rank), backend=be, keep_trace=True)
+    out = greedy_lp(d, run["prompt"], run["max_length"], eos_token_id=run.get("eos"), rng=random.Random(run["seed"] + 1000 * rank), backend=be, keep_trace=True)
     q.put((rank, out.tokens, out.steps, ids_per_step))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("idx", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("idx", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_lp_orchestration_matches_reference_gloo_runs(idx):
     with open(os.path.join(GOLDEN, "e2e_lp.json")) as f:
         runs = json.load(f)["runs"]

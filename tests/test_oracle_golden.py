@@ -139,7 +139,7 @@ def test_lookahead_parallel_matches_reference_gloo_runs():
     for run in d["runs"]:
         model = oracle_model(run)
         res = O.lookahead_greedy(model, run["prompt"], run["W"], run["N"], run["G"], run["max_length"], random.Random(run["seed"]),
-                                 R=run["R"], pool_from_prompt=bool(run.get("pool_from_prompt", 0)))
+                                 R=run["R"], pool_from_prompt=bool(run.get("pool_from_prompt", 0)), eos_token_id=run.get("eos"))
         _check_trace(res, run, run["rank_traces"])
 
 
