@@ -1,12 +1,17 @@
-"""lade/lade_distributed.py:5-12"""
+"""Rank helpers of the lookahead-parallel mode, same two names as the reference exports from `lade`
+(lade/lade_distributed.py:5-12; `from .lade_distributed import *` in lade/__init__.py).
+
+Both read the shared configuration that `config_lade(DIST_WORKERS=...)` fills in; one process drives one MI355X."""
 from .decoding import CONFIG_MAP
 
-
-def get_device():
-    if "LOCAL_RANK" not in CONFIG_MAP:
-        return 0
-    return CONFIG_MAP["LOCAL_RANK"]
+__all__ = ["get_device", "distributed"]
 
 
-def distributed():
-    return "DIST_WORKERS" in CONFIG_MAP and CONFIG_MAP["DIST_WORKERS"] > 1
+def get_device() -> int:
+    """Index of the GPU this process owns: its LOCAL_RANK once lookahead parallelism is configured, GPU 0 before that."""
+    return CONFIG_MAP.get("LOCAL_RANK", 0)
+
+
+def distributed() -> bool:
+    """True when the W window columns are sharded over more than one rank (DIST_WORKERS > 1)."""
+    return CONFIG_MAP.get("DIST_WORKERS", 1) > 1

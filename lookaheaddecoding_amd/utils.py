@@ -13,38 +13,36 @@ import torch.distributed as dist
 from .decoding import CONFIG_MAP, FUNC_MAP
 
 
+# plain settings that config_lade copies into CONFIG_MAP when they are given (None = leave as is)
+_PLAIN_SETTINGS = ("WINDOW_SIZE", "LEVEL", "GUESS_SET_SIZE", "ALWAYS_FWD_ONE", "DEBUG", "SPLIT_FLAG", "POOL_FROM_PROMPT", "USE_FLASH")
+
+
 def config_lade(WINDOW_SIZE=None, LEVEL=None, DEBUG=None, GUESS_SET_SIZE=None, ALWAYS_FWD_ONE=None, SPLIT_FLAG=None,
                 DIST_WORKERS=None, POOL_FROM_PROMPT=None, backend="nccl", USE_FLASH=None):
-    """Same arguments and semantics as the reference.  `backend='nccl'` is RCCL on ROCm.  USE_FLASH is accepted and
-    ignored: there is a single attention path (the fused HIP kernel)."""
-    if WINDOW_SIZE is not None:
-        CONFIG_MAP["WINDOW_SIZE"] = WINDOW_SIZE
-    if LEVEL is not None:
-        CONFIG_MAP["LEVEL"] = LEVEL
-    if GUESS_SET_SIZE is not None:
-        CONFIG_MAP["GUESS_SET_SIZE"] = GUESS_SET_SIZE
-    if ALWAYS_FWD_ONE is not None:
-        CONFIG_MAP["ALWAYS_FWD_ONE"] = ALWAYS_FWD_ONE
-    if DEBUG is not None:
-        CONFIG_MAP["DEBUG"] = DEBUG
-    if SPLIT_FLAG is not None:
-        CONFIG_MAP["SPLIT_FLAG"] = SPLIT_FLAG
-    if POOL_FROM_PROMPT is not None:
-        CONFIG_MAP["POOL_FROM_PROMPT"] = POOL_FROM_PROMPT
+    """Same signature and semantics as the reference's `lade.config_lade` (lade/utils.py:13-37): every argument that is not
+    None overwrites its entry of `lade.decoding.CONFIG_MAP`, `DIST_WORKERS > 1` joins the process group (LOCAL_RANK from the
+    environment; `backend='nccl'` is RCCL on ROCm) and every call starts a fresh log.  USE_FLASH is stored but has no
+    effect: there is a single attention path, the fused HIP kernel."""
+    given = dict(WINDOW_SIZE=WINDOW_SIZE, LEVEL=LEVEL, GUESS_SET_SIZE=GUESS_SET_SIZE, ALWAYS_FWD_ONE=ALWAYS_FWD_ONE, DEBUG=DEBUG,
+                 SPLIT_FLAG=SPLIT_FLAG, POOL_FROM_PROMPT=POOL_FROM_PROMPT, USE_FLASH=USE_FLASH)
+    CONFIG_MAP.update({k: given[k] for k in _PLAIN_SETTINGS if given[k] is not None})
     if DIST_WORKERS is not None and DIST_WORKERS > 1:
-        CONFIG_MAP["DIST_WORKERS"] = DIST_WORKERS
-        CONFIG_MAP["LOCAL_RANK"] = int(os.environ["LOCAL_RANK"])
-        if not dist.is_initialized():
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            if backend == "nccl":
-                torch.cuda.set_device(CONFIG_MAP["LOCAL_RANK"])
-                dist.init_process_group(backend, rank=CONFIG_MAP["LOCAL_RANK"], device_id=torch.device("cuda", CONFIG_MAP["LOCAL_RANK"]))
-            else:
-                dist.init_process_group(backend, rank=CONFIG_MAP["LOCAL_RANK"])
-        assert dist.get_world_size() == DIST_WORKERS, "DIST_WORKERS config should be equal to work size"
-    if USE_FLASH is not None:
-        CONFIG_MAP["USE_FLASH"] = USE_FLASH
+        _join_lookahead_parallel_group(int(DIST_WORKERS), backend)
     CONFIG_MAP["log"] = []            # the reference resets the log on every call (lade/utils.py:37)
+
+
+def _join_lookahead_parallel_group(workers: int, backend: str) -> None:
+    """One process per GPU: rank = LOCAL_RANK (single node, as in the reference, lade/utils.py:28-35)."""
+    rank = int(os.environ["LOCAL_RANK"])
+    CONFIG_MAP["DIST_WORKERS"], CONFIG_MAP["LOCAL_RANK"] = workers, rank
+    if not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            torch.cuda.set_device(rank)
+            dist.init_process_group(backend, rank=rank, device_id=torch.device("cuda", rank))
+        else:
+            dist.init_process_group(backend, rank=rank)
+    assert dist.get_world_size() == workers, "DIST_WORKERS config should be equal to work size"
 
 
 def augment_llama():
@@ -79,17 +77,15 @@ def augment_all():
 
 
 def log_history(clear=False):
-    gen = 0
-    step = 0
-    if "log" in CONFIG_MAP:
-        for log in CONFIG_MAP["log"]:
-            gen += log[0]
-            step += log[1]
+    """Prints the totals of the per-generate log entries [generated, steps, ratio] (lade/utils.py:74-83)."""
+    entries = CONFIG_MAP.get("log", [])
+    gen, step = sum(e[0] for e in entries), sum(e[1] for e in entries)
     if clear:
         CONFIG_MAP["log"] = []
     print("LADE LOG - OVERALL GEN: ", gen, " STEPS: ", step, " AVG COMPRESS RATIO: ", (gen / step) if step > 0 else 0)
 
 
 def save_log(log_dir):
+    """torch.save of the log list to `log_dir` (lade/utils.py:85-87)."""
     if "log" in CONFIG_MAP:
         torch.save(CONFIG_MAP["log"], log_dir)
