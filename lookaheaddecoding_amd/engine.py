@@ -78,6 +78,9 @@ class StepEngine:
         # KV cache: [L][2][Hkv*S_max*d]  (K: [Hkv][S_max][d], V: [Hkv][d][S_max]), zero-initialised
         self.kv = torch.zeros(self.L, 2, self.Hkv * self.S_max * self.d, dtype=dt, device=dev)
         self.kv._lade_meta = dict(Hkv=self.Hkv, d=self.d, S_max=self.S_max)
+        # per-layer views built once: an eager step issues ~10 launches per layer and must not spend its time in tensor indexing
+        self._k_views = [self.kv[li, 0].view(self.Hkv, self.S_max, self.d) for li in range(self.L)]
+        self._vt_views = [self.kv[li, 1].view(self.Hkv, self.d, self.S_max) for li in range(self.L)]
         self.attn_events = None             # set to a list to collect (start, end, T, n_splits) hipEvent pairs per layer
         # workspaces (fixed addresses: graph-capturable, no allocator traffic in the loop)
         qkv_w = (self.H + 2 * self.Hkv) * self.d
@@ -108,10 +111,10 @@ class StepEngine:
 
     # ---- views --------------------------------------------------------------------------------
     def k_cache(self, layer: int) -> torch.Tensor:
-        return self.kv[layer, 0].view(self.Hkv, self.S_max, self.d)
+        return self._k_views[layer]
 
     def vt_cache(self, layer: int) -> torch.Tensor:
-        return self.kv[layer, 1].view(self.Hkv, self.d, self.S_max)
+        return self._vt_views[layer]
 
     def reset(self) -> None:
         self.kv.zero_()
