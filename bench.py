@@ -227,6 +227,8 @@ def main():
         sync()
         eager_ms = (time.perf_counter() - te0) / 4 * 1e3
         evs, eng.attn_events, run.use_graph = eng.attn_events, None, was_graph
+        T_ref = int(round(avg_T))
+        evs = [e for e in evs if e[2] == T_ref] or evs           # launches of the steady shape only (a stray candidate changes T)
         durs = sorted(e0.elapsed_time(e1) * 1e3 for (e0, e1, _, _) in evs)
         if durs:
             # eager launches keep the GPU busy only when a step's GPU time exceeds its host launch time; otherwise the
@@ -234,6 +236,26 @@ def main():
             gpu_bound = eager_ms <= 1.15 * (elapsed / args.steps * 1e3)
             in_situ = {"us": sum(durs) / len(durs), "median_us": durs[len(durs) // 2], "T": evs[-1][2], "n_splits": evs[-1][3], "P": run.P,
                        "launches": len(durs), "eager_ms_per_step": round(eager_ms, 3), "gpu_bound": bool(gpu_bound)}
+
+    # ---- the same pair as a step-time difference: a second decoder over the same engine with the attention launches left
+    # out, same hipGraph mode, same shapes (random weights: no candidates either way) - independent of the host's launch rate
+    graph_delta = None
+    if rank == 0 and not use_lp and not args.no_graph:
+        eng.skip_attn = True
+        d2 = LookaheadDecoder(eng, W, N, 0, use_graph=True)      # no candidates: the garbage logits must not change the step shape
+        d2.start(prompt, rng=random.Random(1))
+        for _ in range(N - 1 + args.warmup):
+            d2.step()
+        sync()
+        tg0 = time.perf_counter()
+        i2 = [d2.step() for _ in range(args.steps)]
+        sync()
+        ms_noattn = (time.perf_counter() - tg0) / args.steps * 1e3
+        eng.skip_attn = False
+        T2 = sum(i["T"] for i in i2) / len(i2)
+        same_class = lambda t: (t <= 32, t <= 64, t <= 96, t <= 128)
+        if abs(T2 - avg_T) <= 4 and all(same_class(i["T"]) == same_class(int(round(avg_T))) for i in i2):      # same GEMM row class throughout
+            graph_delta = {"us": (elapsed / args.steps * 1e3 - ms_noattn) / cfg["layers"] * 1e3, "ms_per_step_without_attention": round(ms_noattn, 3)}
 
     # ---- hot regime, measured last because it overwrites weights.  Random weights never accept a
     # candidate (S = 1).  To time the accept path under load the model is turned into a deterministic successor map:
@@ -284,16 +306,20 @@ def main():
         us_iso = us
         if in_situ is not None and in_situ["T"] == T_k and in_situ["gpu_bound"]:
             us, ns = in_situ["us"], in_situ["n_splits"]
+        elif graph_delta is not None and graph_delta["us"] > 0:
+            us = graph_delta["us"]
         alg = attn_algorithmic_bytes(cfg, T_k, P_end)
         achieved = alg / (us * 1e-6) / 1e9
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
                     "traffic": pmc_traffic(T_k, P_end, ns), "kernel": f"lade::attn_fwd_kernel<{args.dtype},{cfg['head_dim']}> (+combine, n_splits={ns})",
                     "launch_us": round(us, 2), "algorithmic_bytes": alg, "T": T_k, "P": P_end,
                     "launch_us_in_step": None if in_situ is None else {k: (round(v, 2) if isinstance(v, float) else v) for k, v in in_situ.items()},
+                    "launch_us_graph_delta": None if graph_delta is None else {k: (round(v, 2) if isinstance(v, float) else v) for k, v in graph_delta.items()},
                     "launch_us_isolated": round(us_iso, 2),
                     "note": "launch_us = one layer's launch pair (attention + split merge) bracketed by hipEvents on the launch stream INSIDE real decode steps "
                             "(4 eager steady steps after the timed region, every layer), mean - used when those eager steps are GPU bound "
-                            "(launch_us_in_step.gpu_bound), else the isolated value; launch_us_isolated = the same pair launched back to back "
+                            "(launch_us_in_step.gpu_bound), else launch_us_graph_delta = (graph step time - graph step time with the attention launches "
+                            "left out) / layers; launch_us_isolated = the same pair launched back to back "
                             "(lade_time_attn_rot, cycling through the layers' K/V caches so that every launch reads HBM)"}
         hot = hot_regime()
         cpu = None

@@ -82,6 +82,7 @@ class StepEngine:
         self._k_views = [self.kv[li, 0].view(self.Hkv, self.S_max, self.d) for li in range(self.L)]
         self._vt_views = [self.kv[li, 1].view(self.Hkv, self.d, self.S_max) for li in range(self.L)]
         self.attn_events = None             # set to a list to collect (start, end, T, n_splits) hipEvent pairs per layer
+        self.skip_attn = False              # bench.py only: leave the attention launches out (step-time difference = their cost)
         # workspaces (fixed addresses: graph-capturable, no allocator traffic in the loop)
         qkv_w = (self.H + 2 * self.Hkv) * self.d
         self.ws_x = torch.empty(max_T, self.hidden, dtype=dt, device=dev)
@@ -218,12 +219,13 @@ class StepEngine:
                 torch.matmul(h, lw["wqkv"].t(), out=qkv)
                 ops.rope_kv_append(qkv, pos, self.cos, self.sin, self.k_cache(li), self.vt_cache(li), P, H=H, Hkv=Hkv, d=d, dyn_P=dyn_P)
                 q_in = qkv
-            ev = self.attn_events
+            ev = None if self.skip_attn else self.attn_events      # skip_attn: `o` keeps stale values, the logits are meaningless
             if ev is not None:              # bench.py: hipEvents around the attention launch pair, in the real step
                 e0 = torch.cuda.Event(enable_timing=True)
                 e0.record()
-            ops.attn_fwd(q_in, self.k_cache(li), self.vt_cache(li), mask, H=H, Hkv=Hkv, d=d, out=o, n_splits=n_splits,
-                         part_o=self.part_o, part_ml=self.part_ml, dyn_P=dyn_P)
+            if not self.skip_attn:
+                ops.attn_fwd(q_in, self.k_cache(li), self.vt_cache(li), mask, H=H, Hkv=Hkv, d=d, out=o, n_splits=n_splits,
+                             part_o=self.part_o, part_ml=self.part_ml, dyn_P=dyn_P)
             if ev is not None:
                 e1 = torch.cuda.Event(enable_timing=True)
                 e1.record()
