@@ -257,6 +257,32 @@ def main():
         if abs(T2 - avg_T) <= 4 and all(same_class(i["T"]) == same_class(int(round(avg_T))) for i in i2):      # same GEMM row class throughout
             graph_delta = {"us": (elapsed / args.steps * 1e3 - ms_noattn) / cfg["layers"] * 1e3, "ms_per_step_without_attention": round(ms_noattn, 3)}
 
+    # ---- plain autoregressive decoding on the same engine and cache length (one token per forward, T = 1): what
+    # lookahead decoding has to beat; S * (plain step / lookahead step) is its speed-up
+    plain = None
+    if rank == 0 and not use_lp:
+        one_id = torch.full((1,), 5, dtype=torch.int32, device=dev)
+        one_pos = torch.full((1,), P_end, dtype=torch.int32, device=dev)
+        sel0 = torch.zeros(1, dtype=torch.int32, device=dev)
+        m1 = ops.StepMask(T=1, P=P_end, is_prefill=True)
+
+        def plain_step():
+            ops.argmax_rows(eng.forward(one_id, one_pos, m1, sel0, 1))
+
+        for _ in range(3):
+            plain_step()
+        gph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gph):
+            plain_step()
+        sync()
+        tp0 = time.perf_counter()
+        for _ in range(args.steps):
+            gph.replay()
+        sync()
+        ms_plain = (time.perf_counter() - tp0) / args.steps * 1e3
+        plain = {"value": round(1e3 / ms_plain, 2), "unit": "tokens/s", "ms_per_token": round(ms_plain, 3),
+                 "how": f"one-token forward + argmax as a hipGraph at cache length {P_end}, same engine and kernels"}
+
     # ---- hot regime, measured last because it overwrites weights.  Random weights never accept a
     # candidate (S = 1).  To time the accept path under load the model is turned into a deterministic successor map:
     # every layer's o_proj / down_proj zeroed (the residual stream keeps the input embedding) and lm_head row j set to
@@ -334,7 +360,7 @@ def main():
                                    f"W={W} N={N} G={G}, cold regime (untied random weights)", "parallelism": f"lp{world}" if use_lp else "single",
                        "tokens_per_step_T": round(avg_T, 1), "kv_len_end": P_end, "hipgraph": bool(dec.use_graph)},
             "step_compression": round(S, 3), "steps_per_s": round(args.steps / elapsed, 2),
-            "hot_regime": hot, "roofline": roofline, "cpu_baseline": cpu,
+            "hot_regime": hot, "plain_decode": plain, "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if use_lp:
