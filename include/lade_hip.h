@@ -219,15 +219,17 @@ int lade_greedy_post_step(int32_t* ctl, int32_t* window, int32_t wcap, int32_t* 
                           int32_t* tail, int32_t eos, const int32_t* forced, const int32_t* level_override,
                           int32_t* record, void* stream);
 
-/* lookahead parallelism: rank-local verify + record packing, then (after the host's RCCL all-gather of
- * rec_words int32 per rank) the deterministic reduction every rank applies (same phases as above).
- * rec = [first_guess, max_hit, max_hit_idx, n_inp, hits[gs], new tokens[split]]; rec_words >= 4+gs+split.
- * scratch: int32[R*split].  pool_from_prompt / tail / eos: as in lade_greedy_post_step (the EOS scan and the
- * POOL_FROM_PROMPT appends of lade/decoding.py:1167-1177 run identically on every rank); record[1] = n_accept,
- * record[2] = finished. */
-int lade_lp_pack(const int32_t* am_out, const int32_t* am_inp, int32_t n_inp, const int32_t* guess,
-                 const int32_t* am_guess, int32_t g_local, int32_t gs, int32_t split, int32_t* rec,
-                 int32_t rec_words, void* stream);
+/* lookahead parallelism: record packing, then (after the all-gather of rec_words int32 per rank, lade_lp_allgather
+ * or the host's collective) the deterministic reduction every rank applies (same phases as above).
+ * rec = [first_guess, n_inp, g_local, 0 | new tokens[split] | argmax ids of the rank's g_local*gs candidate rows];
+ * rec_words >= 4 + split + g_local*gs.  The candidates are verified inside lade_lp_reduce_apply, on the gathered rows,
+ * against RANK 0's first token - the reference broadcasts `next_tokens` from rank 0 before verifying
+ * (lade/decoding.py:1024, :1071-1096) - so every rank takes the same decision even when 16-bit logits round
+ * differently from rank to rank.  scratch: int32[R*split + G*gs].  pool_from_prompt / tail / eos: as in
+ * lade_greedy_post_step (the EOS scan and the POOL_FROM_PROMPT appends of lade/decoding.py:1167-1177 run identically on
+ * every rank); record[1] = n_accept, record[2] = finished, record[5] = winning rank. */
+int lade_lp_pack(const int32_t* am_out, const int32_t* am_inp, int32_t n_inp, const int32_t* am_guess, int32_t g_local,
+                 int32_t gs, int32_t split, int32_t* rec, int32_t rec_words, void* stream);
 int lade_lp_reduce_apply(const int32_t* all_rec, int32_t R, int32_t rec_words, int32_t split, int32_t* ctl,
                          int32_t* window, int32_t wcap, int32_t* pool_tok, int32_t* pool_cnt, int32_t V, int32_t W,
                          int32_t N, int32_t G, int32_t phase, int32_t* guess_all, int32_t* scratch, int32_t* record,

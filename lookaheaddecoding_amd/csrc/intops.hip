@@ -426,16 +426,15 @@ __global__ __launch_bounds__(64) void greedy_post_step_kernel(int32_t* ctl, int3
 }
 
 // ---- lookahead parallelism: one fixed int32 record per rank per step ------------------------------
-// rec = [first_guess, max_hit, max_hit_idx, n_inp, hits[gs], new tokens[split]]   (lade/decoding.py:1023-1024, 1088-1107)
-__global__ __launch_bounds__(64) void lp_pack_kernel(const int32_t* am_out, const int32_t* am_inp, int n_inp, const int32_t* guess,
+// rec = [first_guess, n_inp, g_local, 0 | new tokens[split] | argmax ids of the rank's g_local*gs candidate rows]
+// (lade/decoding.py:1023-1024, 1088-1107).  The rank does NOT verify its candidates itself: the reference verifies
+// against `next_tokens` broadcast from rank 0 (:1024), so the verification runs on the gathered records, against
+// rank 0's first token, identically on every rank (16-bit logits may round differently from rank to rank).
+__global__ __launch_bounds__(64) void lp_pack_kernel(const int32_t* am_out, const int32_t* am_inp, int n_inp,
                                                      const int32_t* am_guess, int g_local, int gs, int split, int32_t* rec) {
-    __shared__ int32_t hits[LADE_MAX_LEVEL];
-    int mh, mi;
-    verify_greedy(*am_out, guess, am_guess, g_local, gs, &mh, &mi, hits);
-    __syncthreads();
-    if (threadIdx.x == 0) { rec[0] = *am_out; rec[1] = mh; rec[2] = mi; rec[3] = n_inp; }
-    if (threadIdx.x < gs) rec[4 + threadIdx.x] = hits[threadIdx.x];
-    for (int i = threadIdx.x; i < split; i += 64) rec[4 + gs + i] = i < n_inp ? am_inp[i] : 0;
+    if (threadIdx.x == 0) { rec[0] = *am_out; rec[1] = n_inp; rec[2] = g_local; rec[3] = 0; }
+    for (int i = threadIdx.x; i < split; i += 64) rec[4 + i] = i < n_inp ? am_inp[i] : 0;
+    for (int i = threadIdx.x; i < g_local * gs; i += 64) rec[4 + split + i] = am_guess[i];
 }
 
 // Every rank runs the same reduction over the gathered records: first_guess from rank 0
@@ -458,23 +457,31 @@ __global__ __launch_bounds__(64) void lp_reduce_apply_kernel(const int32_t* all_
     const int lst_token = ctl[LADE_CTL_LST_TOKEN];
     const int lst_pos = ctl[LADE_CTL_LST_POS];
     const int fill_level = ctl[LADE_CTL_FILL_LEVEL];
-    const int first_guess = all_rec[0];
+    const int first_guess = all_rec[0];                          // rank 0's first token (decoding.py:1024)
     int total = 0;
     for (int r = (phase == 0 ? R - 1 : 0); r < R; ++r) {
-        const int n = all_rec[(size_t)r * rec_words + 3];
-        for (int i = lane; i < n; i += 64) scratch[total + i] = all_rec[(size_t)r * rec_words + 4 + gs + i];
+        const int n = all_rec[(size_t)r * rec_words + 1];
+        for (int i = lane; i < n; i += 64) scratch[total + i] = all_rec[(size_t)r * rec_words + 4 + i];
         total += n;
     }
-    __syncthreads();
-    int max_hit = 0, win = 0;
+    // the ranks' candidate shards are consecutive (:956-963): their argmax rows concatenate to the rows of all g candidates
+    int32_t* am_all = scratch + R * split;
+    int g_tot = 0;
     if (phase == 2) {
         for (int r = 0; r < R; ++r) {
-            const int mh = all_rec[(size_t)r * rec_words + 1];
-            if (mh > max_hit) { max_hit = mh; win = r; }
+            const int gl = all_rec[(size_t)r * rec_words + 2];
+            for (int i = lane; i < gl * gs; i += 64) am_all[g_tot * gs + i] = all_rec[(size_t)r * rec_words + 4 + split + i];
+            g_tot += gl;
         }
     }
-    if (lane < gs) hits[lane] = max_hit > 0 ? all_rec[(size_t)win * rec_words + 4 + lane] : (lane == 0 ? first_guess : 0);
     __syncthreads();
+    // one scan over the candidates in order with "strictly greater wins" = every rank's best, then the lowest rank among
+    // the best (:1071-1096)
+    int max_hit = 0, win_idx = 0;
+    verify_greedy(first_guess, guess_all, am_all, g_tot, gs, &max_hit, &win_idx, hits);
+    __syncthreads();
+    const int cnt = (g_tot + R - 1) / R;
+    const int win = (max_hit > 0 && cnt > 0) ? win_idx / cnt : 0;
     const int kvcache_len = P + n_input;
     const int new_lst = hits[max_hit];
     if (phase == 2) {
@@ -627,12 +634,12 @@ extern "C" int lade_greedy_post_step(int32_t* ctl, int32_t* window, int32_t wcap
     return check_launch("lade_greedy_post_step");
 }
 
-extern "C" int lade_lp_pack(const int32_t* am_out, const int32_t* am_inp, int32_t n_inp, const int32_t* guess, const int32_t* am_guess,
-                            int32_t g_local, int32_t gs, int32_t split, int32_t* rec, int32_t rec_words, void* stream) {
-    LADE_REQUIRE(am_out && am_inp && rec && n_inp >= 0 && n_inp <= split && gs > 0 && gs < LADE_MAX_LEVEL && rec_words >= 4 + gs + split &&
-                     g_local >= 0 && g_local <= LADE_MAX_GUESS_SET && (g_local == 0 || (guess && am_guess)),
+extern "C" int lade_lp_pack(const int32_t* am_out, const int32_t* am_inp, int32_t n_inp, const int32_t* am_guess, int32_t g_local,
+                            int32_t gs, int32_t split, int32_t* rec, int32_t rec_words, void* stream) {
+    LADE_REQUIRE(am_out && am_inp && rec && n_inp >= 0 && n_inp <= split && gs > 0 && gs < LADE_MAX_LEVEL &&
+                     g_local >= 0 && g_local <= LADE_MAX_GUESS_SET && rec_words >= 4 + split + g_local * gs && (g_local == 0 || am_guess),
                  LADE_E_ARG, "lade_lp_pack: n_inp=%d split=%d gs=%d rec_words=%d g=%d", n_inp, split, gs, rec_words, g_local);
-    hipLaunchKernelGGL(lp_pack_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, am_out, am_inp, n_inp, guess, am_guess, g_local, gs, split, rec);
+    hipLaunchKernelGGL(lp_pack_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, am_out, am_inp, n_inp, am_guess, g_local, gs, split, rec);
     return check_launch("lade_lp_pack");
 }
 
@@ -643,7 +650,7 @@ extern "C" int lade_lp_reduce_apply(const int32_t* all_rec, int32_t R, int32_t r
     const int gs = N - 1;
     POOL_ARGS_OK("lade_lp_reduce_apply");
     LADE_REQUIRE(!pool_from_prompt || tail, LADE_E_ARG, "lade_lp_reduce_apply: POOL_FROM_PROMPT needs the tail buffer");
-    LADE_REQUIRE(all_rec && ctl && window && guess_all && scratch && record && R > 0 && rec_words >= 4 + gs + split && W <= wcap && N >= 3 && N <= LADE_MAX_LEVEL,
+    LADE_REQUIRE(all_rec && ctl && window && guess_all && scratch && record && R > 0 && rec_words >= 4 + split && W <= wcap && N >= 3 && N <= LADE_MAX_LEVEL,
                  LADE_E_ARG, "lade_lp_reduce_apply: R=%d rec_words=%d split=%d", R, rec_words, split);
     hipLaunchKernelGGL(lp_reduce_apply_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, all_rec, R, rec_words, split, ctl, window, wcap,
                        pool_tok, pool_cnt, V, W, N, G, phase, guess_all, scratch, record, pool_from_prompt, tail, eos);

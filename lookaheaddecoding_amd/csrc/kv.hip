@@ -42,7 +42,10 @@ __global__ __launch_bounds__(256) void rope_kv_append_kernel(typename Elem<T>::S
     typedef typename Elem<T>::S S;
     constexpr int VEC = 16 / sizeof(S);
     __shared__ S sm[64][32 + 2];
-    if (dyn_P) P = *dyn_P;
+    if (dyn_P) {
+        P = *dyn_P;
+        if (P + T_ > S_max) return;     // device-side cache length (hipGraph steps): never write K/V rows past the cache
+    }
     const int row_w = (H + 2 * Hkv) * d;
     const int tok_blocks = T_ * bpt;                       // bpt blocks share one token row
     if ((int)blockIdx.x < tok_blocks) {

@@ -19,7 +19,7 @@ import torch
 from . import cabi, ops
 from .cabi import (CTL_FILL_LEVEL, CTL_G, CTL_HITS, CTL_LST_POS, CTL_LST_TOKEN, CTL_N_INPUT, CTL_P, CTL_WLEN, CTL_WORDS,
                    REC_WORDS, call, ptr)
-from .engine import StepEngine
+from .engine import StepEngine, _on_device
 from .ops import StepMask
 
 FUNC_MAP: dict = {}
@@ -95,6 +95,7 @@ class LookaheadDecoder:
         self.W, self.N, self.G, self.gs = W, N, G, N - 1
         self.pool_from_prompt = bool(pool_from_prompt)
         self.lp = lp                      # lookahead-parallel context (parallel.LPContext) or None
+        self.device = engine.device
         self.st = LadeState(engine.V, W, N, G, engine.device, engine.max_T)
         if self.max_step_tokens() > engine.max_T:
             raise cabi.LadeHipError(f"W={W} N={N} G={G} needs {self.max_step_tokens()} tokens per step > engine.max_T={engine.max_T}")
@@ -119,6 +120,7 @@ class LookaheadDecoder:
 
     # ---- stepwise API (bench.py drives single steps; greedy() is start + step until done) ----------
     @torch.no_grad()
+    @_on_device
     def start(self, prompt: Sequence[int], eos_token_id: Optional[int] = None, rng: Optional[random.Random] = None) -> None:
         e, st = self.e, self.st
         W, N, G, gs = self.W, self.N, self.G, self.gs
@@ -145,6 +147,12 @@ class LookaheadDecoder:
     def _buckets(self) -> List[int]:
         G = self.G
         return sorted({0, (G + 3) // 4, (G + 1) // 2, G})
+
+    def _bucket_for(self, g: int) -> int:
+        fits = [b for b in self._graphs if b >= g]
+        if not fits:        # buckets that no longer fit the cache are not captured (_capture_graphs)
+            raise cabi.LadeHipError(f"KV cache exhausted: P={self.P}, a step with {g} candidates no longer fits S_max={self.e.S_max}")
+        return min(fits)
 
     def _graph_body(self, gcap: int, forward_only: bool = False):
         """forward_only (sampling): input assembly + model step + argmax; the fp32 logits of the selected rows stay in
@@ -174,6 +182,10 @@ class LookaheadDecoder:
         for gcap in self._buckets():
             cand_rows = gcap * gs
             T = (N - 1) * W + cand_rows
+            if self.P + T > e.S_max:
+                # the warm-up below runs the whole step body at the current cache length: a bucket that no longer fits would
+                # write its K/V rows past the cache.  Such a bucket can never be replayed either (_step_graph checks), skip it.
+                continue
             rows = [0] + list(range(T - cand_rows - W, T - cand_rows)) + list(range(T - cand_rows, T))
             self._graph_sel[gcap] = torch.tensor(rows, dtype=torch.int32, device=e.device)
             self._graph_splits[gcap] = e.n_splits_for(T, min(e.S_max, max(self.P + T, 1024)))
@@ -194,12 +206,13 @@ class LookaheadDecoder:
             self._graphs[gcap] = g
         self._graph = "forward" if forward_only else "step"
         self._graph_eos = self.eos
+        self._graph_gen = e.generation
 
     def _step_graph(self) -> dict:
         e, st = self.e, self.st
-        if self._graph != "step" or self._graph_eos != self.eos:
+        if self._graph != "step" or self._graph_eos != self.eos or self._graph_gen != e.generation:
             self._capture_graphs()
-        gcap = min(b for b in self._graphs if b >= self.g)
+        gcap = self._bucket_for(self.g)
         T = self._graph_T[gcap]
         if abs(e.n_splits_for(T, self.P + T) - self._graph_splits[gcap]) >= 2:      # the cache outgrew the captured KV split count
             self._capture_graphs()
@@ -218,6 +231,7 @@ class LookaheadDecoder:
                     first_guess=rec[6], g_next=self.g, P_after=self.P, phase=2)
 
     @torch.no_grad()
+    @_on_device
     def step(self, keep_trace: bool = False) -> dict:
         """One decode step = one model forward over T tokens + the device-side post-step; returns the
         host-visible record (accepted tokens, max_hit ...)."""
@@ -227,39 +241,27 @@ class LookaheadDecoder:
         if self.use_graph and self.steps > 0 and fill_level >= N - 2:
             return self._step_graph()
         if self.steps == 0:                                          # prefill: prompt + L0, plain causal
-            phase, n_input = 0, len(prompt)
+            phase = 0
             ids_h = prompt + self.window0
-            total = len(ids_h)
-            # long prompts run as causal chunks of <= max_T tokens over the growing cache; only the last
-            # chunk (which holds the last prompt token and the whole window) needs logits
-            last_len = min(total, max(e.max_T, len(self.window0) + 1))
-            done = 0
-            while total - done > last_len:
-                n = min(e.max_T, total - last_len - done)
-                st.ids[:n].copy_(torch.tensor(ids_h[done:done + n], dtype=torch.int32))
-                st.pos[:n].copy_(torch.arange(done, done + n, dtype=torch.int32))
-                e.forward(st.ids, st.pos, StepMask(T=n, P=done, is_prefill=True), st.sel, 0)
-                done += n
-            T = total - done
-            st.ids[:T].copy_(torch.tensor(ids_h[done:], dtype=torch.int32))
-            st.pos[:T].copy_(torch.arange(done, total, dtype=torch.int32))
-            mask = StepMask(T=T, P=done, is_prefill=True)
             n_inp, cand_rows = len(self.window0), 0
-            n_input = len(prompt) - done                             # out row = last prompt token of this chunk
+            # rows whose logits are read: the last prompt token and the window (:1578-1606)
+            logits, done = e.prefill(ids_h, [len(prompt) - 1] + list(range(len(prompt), len(ids_h))))
+            T, P_before = len(ids_h) - done, done
+            n_input = len(prompt) - done                             # out row = last prompt token of the last chunk
         else:
             phase = 2 if fill_level >= N - 2 else 1
             n_input = 1
             ls = self._level_sizes(fill_level)
             cand_rows = g * gs if phase == 2 else 0
             mask = StepMask.from_levels(n_input, ls, cand_rows, gs, P)
-            T = mask.T
+            T, P_before = mask.T, P
             call("lade_build_inputs", None, None, n_input, ptr(st.window), st.wcap, ptr(st.ctl), min(fill_level, N - 2), 0, -1,
                  ptr(st.guess), g if phase == 2 else 0, gs, cand_rows, ptr(st.ids), ptr(st.pos), None)
             n_inp = ls[-1]
-        # rows whose logits are needed: out row, last level's rows, candidate rows (:1578-1606)
-        rows = [n_input - 1] + list(range(T - cand_rows - n_inp, T - cand_rows)) + list(range(T - cand_rows, T))
-        n_sel = self._set_sel(rows)
-        logits = e.forward(st.ids, st.pos, mask, st.sel, n_sel)
+            # rows whose logits are needed: out row, last level's rows, candidate rows (:1578-1606)
+            rows = [n_input - 1] + list(range(T - cand_rows - n_inp, T - cand_rows)) + list(range(T - cand_rows, T))
+            n_sel = self._set_sel(rows)
+            logits = e.forward(st.ids, st.pos, mask, st.sel, n_sel)
         ops.argmax_rows(logits, out=st.am)
         call("lade_greedy_post_step", ptr(st.ctl), ptr(st.window), st.wcap, ptr(st.pool_tok), ptr(st.pool_cnt), st.V, W, N, G,
              ptr(st.am), n_inp, ptr(st.guess), T, cand_rows, phase, int(self.pool_from_prompt), ptr(st.tail), self.eos, None, None, ptr(st.record))
@@ -272,10 +274,11 @@ class LookaheadDecoder:
         if phase != 2:
             self.fill_level += 1
         self.finished_by_eos = bool(eos_hit)
-        return dict(T=T, P_before=mask.P, n_input=n_input, max_hit=max_hit, max_hit_idx=rec[5], accepted=list(accepted),
+        return dict(T=T, P_before=P_before, n_input=n_input, max_hit=max_hit, max_hit_idx=rec[5], accepted=list(accepted),
                     first_guess=rec[6], g_next=self.g, P_after=self.P, phase=phase)
 
     @torch.no_grad()
+    @_on_device
     def greedy(self, prompt: Sequence[int], max_length: int, eos_token_id: Optional[int] = None,
                rng: Optional[random.Random] = None, keep_trace: bool = False, on_step=None) -> GenOut:
         """`jacobi_greedy_search_multilevel` (lade/decoding.py:697-1259), single GPU or lookahead parallel.
@@ -303,6 +306,7 @@ class LookaheadDecoder:
 
     # ---- sampling ------------------------------------------------------------------------------------
     @torch.no_grad()
+    @_on_device
     def sample(self, prompt: Sequence[int], max_length: int, warp=None, eos_token_id: Optional[int] = None,
                rng: Optional[random.Random] = None, torch_gen: Optional[torch.Generator] = None, keep_trace: bool = False,
                on_step=None) -> GenOut:
@@ -327,30 +331,21 @@ class LookaheadDecoder:
         trace: List[dict] = []
         while True:
             prompt_l, P, g, fill_level = self.prompt, self.P, self.g, self.fill_level
+            P_before = P
             if self.steps == 0:
-                phase, n_input = 0, len(prompt_l)
+                phase = 0
                 ids_h = prompt_l + self.window0
-                total = len(ids_h)
-                last_len = min(total, max(e.max_T, len(self.window0) + 1))
-                done = 0
-                while total - done > last_len:
-                    n = min(e.max_T, total - last_len - done)
-                    st.ids[:n].copy_(torch.tensor(ids_h[done:done + n], dtype=torch.int32))
-                    st.pos[:n].copy_(torch.arange(done, done + n, dtype=torch.int32))
-                    e.forward(st.ids, st.pos, StepMask(T=n, P=done, is_prefill=True), st.sel, 0)
-                    done += n
-                T = total - done
-                st.ids[:T].copy_(torch.tensor(ids_h[done:], dtype=torch.int32))
-                st.pos[:T].copy_(torch.arange(done, total, dtype=torch.int32))
-                mask = StepMask(T=T, P=done, is_prefill=True)
                 n_inp, cand_rows = len(self.window0), 0
-                n_input = len(prompt_l) - done
+                logits, done = e.prefill(ids_h, [len(prompt_l) - 1] + list(range(len(prompt_l), len(ids_h))))
+                logits = logits.float()
+                ops.argmax_rows(logits, out=st.am)
+                T, P_before = len(ids_h) - done, done
             elif self.use_graph and fill_level >= N - 2:
                 # steady step: input assembly + model step + argmax replayed as one hipGraph (candidate rows padded to the bucket)
-                if self._graph != "forward":
+                if self._graph != "forward" or self._graph_gen != e.generation:
                     self._capture_graphs(forward_only=True)
                 phase, n_input, n_inp = 2, 1, W
-                gcap = min(b for b in self._graphs if b >= g)
+                gcap = self._bucket_for(g)
                 T, cand_rows = self._graph_T[gcap], gcap * gs
                 if abs(e.n_splits_for(T, P + T) - self._graph_splits[gcap]) >= 2:
                     self._capture_graphs(forward_only=True)
@@ -369,7 +364,7 @@ class LookaheadDecoder:
                 call("lade_build_inputs", None, None, n_input, ptr(st.window), st.wcap, ptr(st.ctl), min(fill_level, N - 2), 0, -1,
                      ptr(st.guess), g if phase == 2 else 0, gs, cand_rows, ptr(st.ids), ptr(st.pos), None)
                 n_inp = ls[-1]
-            if not (self.use_graph and self.steps > 0 and fill_level >= N - 2):
+            if self.steps > 0 and not (self.use_graph and fill_level >= N - 2):
                 rows = [n_input - 1] + list(range(T - cand_rows - n_inp, T - cand_rows)) + list(range(T - cand_rows, T))
                 n_sel = self._set_sel(rows)
                 logits = e.forward(st.ids, st.pos, mask, st.sel, n_sel).float()    # logits.float(), modeling_llama.py:1544
@@ -411,7 +406,7 @@ class LookaheadDecoder:
             if phase != 2:
                 self.fill_level += 1
             if keep_trace:
-                trace.append(dict(T=T, P_before=mask.P, max_hit=max_hit, max_hit_idx=max_hit_idx, accepted=list(accepted), phase=phase))
+                trace.append(dict(T=T, P_before=P_before, max_hit=max_hit, max_hit_idx=max_hit_idx, accepted=list(accepted), phase=phase))
             if eos_hit or len(self.tokens) >= max_length:
                 break
         generated = min(len(self.tokens), max_length) - len(self.prompt)

@@ -28,14 +28,59 @@ from . import cabi, ops
 from .ops import StepMask
 
 
-def rope_tables(d: int, max_pos: int, theta: float, dtype, device):
-    """cos/sin [max_pos, d]: fp32 math, then cast - exactly LlamaRotaryEmbedding
-    (lade/models/modeling_llama.py:238-256, cast at :264-265)."""
+def rope_inv_freq(d: int, theta: float, scaling: Optional[dict] = None) -> torch.Tensor:
+    """inv_freq [d/2] in fp32.  Default: LlamaRotaryEmbedding (lade/models/modeling_llama.py:238-246).  `llama3`: the
+    frequency-dependent rescaling newer Llama checkpoints carry in `rope_scaling` (low frequencies divided by `factor`,
+    a smooth blend between `original_max_position_embeddings / low_freq_factor` and `/ high_freq_factor` wavelengths)."""
     inv_freq = 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+    kind = None if not scaling else scaling.get("rope_type", scaling.get("type"))
+    if kind == "llama3":
+        factor = float(scaling["factor"])
+        lo, hi = float(scaling.get("low_freq_factor", 1.0)), float(scaling.get("high_freq_factor", 4.0))
+        old_len = float(scaling.get("original_max_position_embeddings", 8192))
+        wavelen = 2 * math.pi / inv_freq
+        scaled = torch.where(wavelen > old_len / lo, inv_freq / factor, inv_freq)
+        smooth = (old_len / wavelen - lo) / (hi - lo)
+        blended = (1 - smooth) * scaled / factor + smooth * scaled
+        medium = ~(wavelen < old_len / hi) & ~(wavelen > old_len / lo)
+        inv_freq = torch.where(medium, blended, scaled)
+    elif kind not in (None, "default", "linear"):
+        raise cabi.LadeHipError(f"rope_scaling type {kind!r} is not implemented (default, linear and llama3 are; 'dynamic' rebuilds its "
+                                f"tables as the sequence grows, lade/models/modeling_llama.py:292-318, and is refused rather than approximated)")
+    return inv_freq
+
+
+def rope_tables(d: int, max_pos: int, theta: float, dtype, device, scaling: Optional[dict] = None):
+    """cos/sin [max_pos, d]: fp32 math, then cast - exactly LlamaRotaryEmbedding
+    (lade/models/modeling_llama.py:238-256, cast at :264-265); `linear` scaling divides the positions by `factor`
+    (LlamaLinearScalingRotaryEmbedding, :268-289)."""
+    inv_freq = rope_inv_freq(d, theta, scaling)
     t = torch.arange(max_pos, dtype=torch.float32)
+    if scaling and scaling.get("rope_type", scaling.get("type")) == "linear":
+        t = t / float(scaling["factor"])
     freqs = torch.outer(t, inv_freq)
     emb = torch.cat((freqs, freqs), dim=-1)
     return emb.cos().to(dtype).to(device).contiguous(), emb.sin().to(dtype).to(device).contiguous()
+
+
+def _on_device(fn):
+    """Runs an engine / decoder method with the engine's GPU as the current device: the C-ABI calls launch on the CURRENT
+    device's current stream, so a model on cuda:k driven from a thread whose current device is another GPU would otherwise
+    launch cuda:k pointers on the wrong device."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        dev = self.device
+        if torch.cuda.current_device() == dev.index:
+            return fn(self, *a, **k)
+        with torch.cuda.device(dev):
+            return fn(self, *a, **k)
+    return wrapped
+
+
+_TUNE_CACHE: dict = {}
+_TUNE_LOCK = __import__("threading").Lock()
 
 
 class StepEngine:
@@ -56,7 +101,7 @@ class StepEngine:
         self.L, self.H, self.Hkv, self.d, self.V = cfg["layers"], cfg["heads"], cfg["kv_heads"], cfg["head_dim"], cfg["vocab"]
         self.eps = float(cfg["eps"])
         self.S_max = ((max_seq + 63) // 64) * 64
-        self.max_T = max_T
+        self.generation = 0                  # bumped whenever buffers are re-allocated (captured graphs become stale)
         dev, dt = self.device, dtype
 
         def W(k):
@@ -74,16 +119,43 @@ class StepEngine:
                 wo=W(p + "wo").contiguous(),
                 wgu=torch.cat([W(p + "wg"), W(p + "wu")], dim=0).contiguous(),
                 wd=W(p + "wd").contiguous()))
-        self.cos, self.sin = rope_tables(self.d, max(cfg.get("max_pos", 4096), self.S_max), cfg.get("rope_theta", 10000.0), dt, dev)
-        # KV cache: [L][2][Hkv*S_max*d]  (K: [Hkv][S_max][d], V: [Hkv][d][S_max]), zero-initialised
-        self.kv = torch.zeros(self.L, 2, self.Hkv * self.S_max * self.d, dtype=dt, device=dev)
-        self.kv._lade_meta = dict(Hkv=self.Hkv, d=self.d, S_max=self.S_max)
-        # per-layer views built once: an eager step issues ~10 launches per layer and must not spend its time in tensor indexing
-        self._k_views = [self.kv[li, 0].view(self.Hkv, self.S_max, self.d) for li in range(self.L)]
-        self._vt_views = [self.kv[li, 1].view(self.Hkv, self.d, self.S_max) for li in range(self.L)]
+        self._alloc_cache(self.S_max)
         self.attn_events = None             # set to a list to collect (start, end, T, n_splits) hipEvent pairs per layer
         self.skip_attn = False              # bench.py only: leave the attention launches out (step-time difference = their cost)
-        # workspaces (fixed addresses: graph-capturable, no allocator traffic in the loop)
+        self.max_splits = 32
+        # hand-written weight-streaming GEMM (split-K partials consumed by the fused glue kernels) for steps of
+        # <= 128 tokens; every (N, K, row class) is timed against the library GEMM once and the faster one is kept
+        self.custom_gemm = dt != torch.float32 and os.environ.get("LADE_GEMM", "1") != "0" and self.d % 16 == 0 and self.hidden % 64 == 0 and self.inter % 64 == 0
+        self.gemm_cfg = {}
+        self._alloc_workspaces(max_T)
+        try:
+            self.n_cu = torch.cuda.get_device_properties(self.device.index).multi_processor_count
+        except AssertionError:      # device count not initialised on this thread yet
+            self.n_cu = 256
+
+    def _alloc_cache(self, S_max: int, keep_rows: int = 0) -> None:
+        """KV cache [L][2][Hkv*S_max*d] (K: [Hkv][S_max][d], V: [Hkv][d][S_max]), zero-initialised; RoPE tables for it.
+        keep_rows > 0: the first keep_rows rows of the previous cache are carried over (growth under a live sequence)."""
+        dev, dt = self.device, self.dtype
+        old = getattr(self, "kv", None)
+        old_k, old_v = getattr(self, "_k_views", None), getattr(self, "_vt_views", None)
+        self.S_max = S_max
+        self.cos, self.sin = rope_tables(self.d, max(self.cfg.get("max_pos", 4096), S_max), self.cfg.get("rope_theta", 10000.0), dt, dev,
+                                         self.cfg.get("rope_scaling"))
+        self.kv = torch.zeros(self.L, 2, self.Hkv * S_max * self.d, dtype=dt, device=dev)
+        self.kv._lade_meta = dict(Hkv=self.Hkv, d=self.d, S_max=S_max)
+        # per-layer views built once: an eager step issues ~10 launches per layer and must not spend its time in tensor indexing
+        self._k_views = [self.kv[li, 0].view(self.Hkv, S_max, self.d) for li in range(self.L)]
+        self._vt_views = [self.kv[li, 1].view(self.Hkv, self.d, S_max) for li in range(self.L)]
+        if old is not None and keep_rows > 0:
+            for li in range(self.L):
+                self._k_views[li][:, :keep_rows].copy_(old_k[li][:, :keep_rows])
+                self._vt_views[li][:, :, :keep_rows].copy_(old_v[li][:, :, :keep_rows])
+
+    def _alloc_workspaces(self, max_T: int) -> None:
+        """fixed addresses: graph-capturable, no allocator traffic in the loop"""
+        dev, dt = self.device, self.dtype
+        self.max_T = max_T
         qkv_w = (self.H + 2 * self.Hkv) * self.d
         self.ws_x = torch.empty(max_T, self.hidden, dtype=dt, device=dev)
         self.ws_h = torch.empty(max_T, self.hidden, dtype=dt, device=dev)
@@ -92,23 +164,26 @@ class StepEngine:
         self.ws_o = torch.empty(max_T, self.H * self.d, dtype=dt, device=dev)
         self.ws_gu = torch.empty(max_T, 2 * self.inter, dtype=dt, device=dev)
         self.ws_a = torch.empty(max_T, self.inter, dtype=dt, device=dev)
-        self.max_splits = 32
         if dt != torch.float32:
             self.part_o = torch.empty(self.max_splits * self.H * max_T * self.d, dtype=dt, device=dev)
             self.part_ml = torch.empty(self.max_splits * self.H * max_T * 2, dtype=torch.float32, device=dev)
         else:
             self.part_o = self.part_ml = None
-        # hand-written weight-streaming GEMM (split-K partials consumed by the fused glue kernels) for steps of
-        # <= 128 tokens; every (N, K, row class) is timed against the library GEMM once and the faster one is kept
-        self.custom_gemm = dt != torch.float32 and os.environ.get("LADE_GEMM", "1") != "0" and self.d % 16 == 0 and self.hidden % 64 == 0 and self.inter % 64 == 0
-        self.gemm_cfg = {}
         if self.custom_gemm:
             self.ws_part = torch.empty(16 * 128 * max(qkv_w, 2 * self.inter, self.hidden), dtype=torch.float32, device=dev)
             self.ws_q = torch.empty(max_T, self.H * self.d, dtype=dt, device=dev)
-        try:
-            self.n_cu = torch.cuda.get_device_properties(self.device.index).multi_processor_count
-        except AssertionError:      # device count not initialised on this thread yet
-            self.n_cu = 256
+
+    def grow(self, max_seq: int, max_T: int, keep_rows: int = 0) -> None:
+        """Enlarges the KV cache and / or the step workspaces in place (the fused weights stay): the first keep_rows cache
+        rows survive.  Captured hipGraphs over the old buffers are the caller's to drop (LookaheadDecoder re-captures when
+        `generation` changes)."""
+        S_new = ((max_seq + 63) // 64) * 64
+        if S_new > self.S_max:
+            self._alloc_cache(S_new, keep_rows)
+            self.generation += 1
+        if max_T > self.max_T:
+            self._alloc_workspaces(max_T)
+            self.generation += 1
 
     # ---- views --------------------------------------------------------------------------------
     def k_cache(self, layer: int) -> torch.Tensor:
@@ -142,6 +217,19 @@ class StepEngine:
             return self.gemm_cfg[key]
         ws = [lw[name] for lw in self.layers]
         N, K = ws[0].shape
+        # one decision per (shape, row class, dtype) and process: engines of the same model (lookahead-parallel ranks run as
+        # threads, a decoder rebuilt on the same weights) must pick the same kernel, or their 16-bit results round differently
+        gkey = (int(N), int(K), mclass, str(self.dtype))
+        with _TUNE_LOCK:
+            if gkey in _TUNE_CACHE:
+                self.gemm_cfg[key] = _TUNE_CACHE[gkey]
+                return self.gemm_cfg[key]
+            best = self._tune_timed(name, mclass, ws, N, K)
+            _TUNE_CACHE[gkey] = best
+        self.gemm_cfg[key] = best
+        return best
+
+    def _tune_timed(self, name: str, mclass: int, ws, N: int, K: int):
         a = torch.randn({32: 30, 64: 60, 96: 92, 128: 128}[mclass], K, device=self.device).to(self.dtype)
         out = torch.empty(a.shape[0], N, dtype=self.dtype, device=self.device)
         cands = []
@@ -178,10 +266,24 @@ class StepEngine:
             t = time_it(lambda i: ops.gemm_parts(a, ws[i % len(ws)], self.ws_part, S, bn, mb, mt, nt))
             if t < t_best:
                 best, t_best = (mb, bn, S, mt, nt), t
-        self.gemm_cfg[key] = best
         return best
 
+    GEMM_NAMES = ("wqkv", "wo", "wgu", "wd")
+
+    def tune_all(self) -> dict:
+        """Every (projection, row class) decision of this engine as a plain dict (lookahead parallelism: rank 0 tunes,
+        the other ranks adopt its table through `adopt_gemm_cfg`, so that all replicas round alike)."""
+        if not self.custom_gemm:
+            return {}
+        return {f"{n}:{m}": self._tune(n, m) for n in self.GEMM_NAMES for m in (32, 64, 96, 128)}
+
+    def adopt_gemm_cfg(self, table: dict) -> None:
+        for k, v in table.items():
+            n, m = k.split(":")
+            self.gemm_cfg[(n, int(m))] = None if v is None else tuple(v)
+
     # ---- one forward -----------------------------------------------------------------------------
+    @_on_device
     def forward(self, ids: torch.Tensor, pos: torch.Tensor, mask: StepMask, sel_rows: torch.Tensor, n_sel: int,
                 dyn_P: Optional[torch.Tensor] = None, n_splits: Optional[int] = None) -> torch.Tensor:
         """ids/pos: device int32 [>=T]; mask describes the step; sel_rows: device int32 [n_sel] rows whose
@@ -257,8 +359,43 @@ class StepEngine:
         hn = ops.add_rmsnorm(xs, rs, self.norm_w, self.eps)
         return torch.matmul(hn, self.lm_head.t())
 
+    # ---- prefill: plain causal rows over the growing cache ---------------------------------------------
+    @torch.no_grad()
+    @_on_device
+    def prefill(self, ids: Sequence[int], rows: Sequence[int], P0: int = 0, pos: Optional[Sequence[int]] = None):
+        """Feeds `ids` (prompt + first window level; lade/models/modeling_llama.py:124-130 plain causal mask, :1527
+        `is_prefill`) on top of P0 cached rows as causal chunks of <= max_T tokens.  Only the last chunk runs lm_head,
+        and only on `rows` (indices into `ids`; the reference runs it over the whole prompt, :1541-1544), so the last
+        chunk is sized to hold every requested row.  pos: positions of the tokens (default P0, P0+1, ...).
+        Returns (logits [len(rows), V] in the model dtype, done) with done = tokens fed by the cache-only chunks
+        (the last chunk is the step `T = len(ids) - done` at `P = P0 + done`).  The one prefill loop of the package:
+        the greedy / sampling / lookahead-parallel loops and hf.jforward_multilevel all come through here."""
+        total = len(ids)
+        if total == 0 or not rows:
+            raise cabi.LadeHipError("prefill needs at least one token and one logits row")
+        need = total - min(rows)                                  # the last chunk must contain every requested row
+        last_len = min(total, max(self.max_T, need))
+        if last_len > self.max_T:
+            raise cabi.LadeHipError(f"prefill needs logits of the last {need} tokens in one chunk > engine.max_T={self.max_T}")
+        if P0 + total > self.S_max:
+            raise cabi.LadeHipError(f"prefill of {total} tokens at P={P0} exceeds the KV cache (S_max={self.S_max})")
+        dev = self.device
+        t_ids = torch.tensor([int(t) for t in ids], dtype=torch.int32).to(dev, non_blocking=True)
+        t_pos = (torch.arange(P0, P0 + total, dtype=torch.int32) if pos is None else torch.tensor([int(t) for t in pos], dtype=torch.int32)).to(dev, non_blocking=True)
+        none_sel = torch.zeros(1, dtype=torch.int32, device=dev)
+        done = 0
+        while total - done > last_len:
+            n = min(self.max_T, total - last_len - done)
+            self.forward(t_ids[done:done + n], t_pos[done:done + n], StepMask(T=n, P=P0 + done, is_prefill=True), none_sel, 0)
+            done += n
+        sel = torch.tensor([int(r) - done for r in rows], dtype=torch.int32).to(dev, non_blocking=True)
+        T = total - done
+        logits = self.forward(t_ids[done:], t_pos[done:], StepMask(T=T, P=P0 + done, is_prefill=True), sel, len(rows))
+        return logits, done
+
     # ---- plain causal decoding on the same kernels (the sequence lookahead must reproduce) ------
     @torch.no_grad()
+    @_on_device
     def plain_greedy(self, prompt: Sequence[int], max_length: int, eos_token_id: Optional[int] = None) -> List[int]:
         self.reset()
         ids = list(prompt)

@@ -27,17 +27,43 @@ from .engine import StepEngine
 _ENGINE_ATTR = "_lade_engine"
 
 
-def config_from_hf(model) -> dict:
-    c = model.config
-    heads = c.num_attention_heads
-    head_dim = getattr(c, "head_dim", None) or c.hidden_size // heads
+def _rope_params(c):
+    """(theta, scaling dict or None) from either config generation (4.36: rope_theta / rope_scaling; 5.x: rope_parameters)."""
+    rp = getattr(c, "rope_parameters", None)
+    rp = dict(rp) if isinstance(rp, dict) else {}
     theta = getattr(c, "rope_theta", None)
     if theta is None:
-        rp = getattr(c, "rope_parameters", None) or {}
-        theta = rp.get("rope_theta", 10000.0) if isinstance(rp, dict) else 10000.0
+        theta = rp.get("rope_theta", 10000.0)
+    scaling = getattr(c, "rope_scaling", None)
+    if scaling is None and rp.get("rope_type", rp.get("type", "default")) not in (None, "default"):
+        scaling = rp
+    if isinstance(scaling, dict) and scaling.get("rope_type", scaling.get("type", "default")) in (None, "default"):
+        scaling = None
+    return float(theta), scaling
+
+
+def config_from_hf(model) -> dict:
+    """Engine config of an HF LlamaForCausalLM.  Anything the HIP step does not implement fails loudly here - the reference
+    only patches the Llama classes (lade/utils.py:40-56), so any other architecture raises there too."""
+    c = model.config
+    if type(model).__name__ != "LlamaForCausalLM" or getattr(c, "model_type", "llama") != "llama":
+        raise cabi.LadeHipError(f"lookahead decoding supports LlamaForCausalLM only (got {type(model).__name__}, model_type="
+                                f"{getattr(c, 'model_type', None)!r}); the reference patches the Llama classes only (lade/utils.py:40-56)")
+    theta, scaling = _rope_params(c)
+    if scaling is not None:
+        kind = scaling.get("rope_type", scaling.get("type"))
+        if kind not in ("linear", "dynamic", "llama3"):
+            raise cabi.LadeHipError(f"rope_scaling type {kind!r} is not implemented by the HIP step (default, linear, dynamic, llama3 are)")
+    if getattr(c, "attention_bias", False) or getattr(c, "mlp_bias", False):
+        raise cabi.LadeHipError("projection biases are not supported (Llama-2 has none)")
+    if getattr(c, "pretraining_tp", 1) not in (None, 1):
+        raise cabi.LadeHipError("pretraining_tp > 1 is out of scope (DESIGN.md section 8)")
+    heads = c.num_attention_heads
+    head_dim = getattr(c, "head_dim", None) or c.hidden_size // heads
     return dict(hidden=c.hidden_size, inter=c.intermediate_size, layers=c.num_hidden_layers, heads=heads,
                 kv_heads=getattr(c, "num_key_value_heads", heads) or heads, head_dim=head_dim, vocab=c.vocab_size,
-                eps=float(c.rms_norm_eps), rope_theta=float(theta), max_pos=int(getattr(c, "max_position_embeddings", 4096)))
+                eps=float(c.rms_norm_eps), rope_theta=theta, rope_scaling=scaling,
+                max_pos=int(getattr(c, "max_position_embeddings", 4096)))
 
 
 def weights_from_hf(model) -> dict:
@@ -57,19 +83,24 @@ def weights_from_hf(model) -> dict:
     return w
 
 
-def get_engine(model, need_seq: int, need_T: int) -> StepEngine:
-    """The model's cached StepEngine, rebuilt when the KV capacity or the step width must grow."""
-    if type(model).__name__ not in ("LlamaForCausalLM",) and not hasattr(model, "model"):
-        raise cabi.LadeHipError(f"lookahead decoding supports Llama-family models (got {type(model).__name__})")
+def get_engine(model, need_seq: int, need_T: int, keep_rows: int = 0) -> StepEngine:
+    """The model's cached StepEngine.  Built once over the module's own weight tensors; when a later call needs a longer
+    KV cache or a wider step, the cache / workspaces grow in place (`StepEngine.grow`: the first keep_rows cache rows
+    survive, so an `EngineCache` a caller still holds stays valid) - the fused weight copies are never duplicated."""
     eng: Optional[StepEngine] = getattr(model, _ENGINE_ATTR, None)
-    if eng is not None and eng.S_max >= need_seq and eng.max_T >= need_T:
+    if eng is not None:
+        if eng.S_max < need_seq or eng.max_T < need_T:
+            eng.grow(max(need_seq, 2 * eng.S_max if eng.S_max < need_seq else 0), need_T, keep_rows)
         return eng
     dev = model.lm_head.weight.device
     if dev.type != "cuda":
         raise cabi.LadeHipError("USE_LADE=1 needs the model on a GPU (the HIP hot path has no CPU fallback)")
     dtype = model.lm_head.weight.dtype
-    eng = StepEngine(config_from_hf(model), weights_from_hf(model), dtype=dtype, device=dev,
-                     max_seq=max(need_seq, 2048), max_T=max(need_T, 512))
+    cfg = config_from_hf(model)
+    # sized for the model's whole context window when that is affordable (<= 8 GiB of K/V), otherwise for what this call needs
+    kv_bytes_per_row = 2 * cfg["layers"] * cfg["kv_heads"] * cfg["head_dim"] * model.lm_head.weight.element_size()
+    full = cfg["max_pos"] if cfg["max_pos"] * kv_bytes_per_row <= (8 << 30) else 0
+    eng = StepEngine(cfg, weights_from_hf(model), dtype=dtype, device=dev, max_seq=max(need_seq, 2048, full), max_T=max(need_T, 512))
     setattr(model, _ENGINE_ATTR, eng)
     return eng
 
@@ -158,29 +189,23 @@ def jforward_multilevel(self, input_ids=None, past_tokens=None, guess_tokens=Non
     T = len(ids)
     is_prefill = past_tokens[1] is None
     window = level_sizes[fill_level]
-    eng = get_engine(self, past_size + T + 64, min(T, 512))
+    # a prefill is chunked by the engine; any other step must fit one forward (the reference default W=60 N=8 G=60 feeds 847 rows)
+    eng = get_engine(self, past_size + T + 64, 512 if is_prefill else max(T, 512), keep_rows=past_size)
     if past_key_values is None:
         eng.reset()
     elif past_key_values.engine is not eng:
-        raise cabi.LadeHipError("past_key_values belongs to another step engine (the engine was rebuilt to grow its KV capacity)")
+        raise cabi.LadeHipError("past_key_values belongs to another model's step engine")
     dev = eng.device
     rows = [n_input - 1] + list(range(T - lguess - window, T - lguess)) + list(range(T - lguess, T))
-    done = 0
-    if is_prefill and T > eng.max_T:                  # long prompt: cache-filling chunks first (plain causal rows)
-        last_len = max(T - (n_input - 1), eng.max_T)  # the last chunk holds every row whose logits are read
-        while T - done > last_len:
-            n = min(eng.max_T, T - last_len - done)
-            eng.forward(torch.tensor(ids[done:done + n], dtype=torch.int32, device=dev), torch.tensor(pos[done:done + n], dtype=torch.int32, device=dev),
-                        StepMask(T=n, P=past_size + done, is_prefill=True), torch.zeros(1, dtype=torch.int32, device=dev), 0)
-            done += n
-    Tc = T - done
-    if Tc > eng.max_T:
-        raise cabi.LadeHipError(f"step of {Tc} tokens exceeds the engine's max_T={eng.max_T}")
-    mask = (StepMask(T=Tc, P=past_size + done, is_prefill=True) if is_prefill
-            else StepMask.from_levels(n_input, level_sizes, lguess, gs, past_size))
-    sel = torch.tensor([r - done for r in rows], dtype=torch.int32, device=dev)
-    logits = eng.forward(torch.tensor(ids[done:], dtype=torch.int32, device=dev), torch.tensor(pos[done:], dtype=torch.int32, device=dev),
-                         mask, sel, len(rows)).float()
+    if is_prefill:                                    # prompt (+ first window level): causal chunks over the growing cache
+        logits, _ = eng.prefill(ids, rows, P0=past_size, pos=pos)
+        logits = logits.float()
+    else:
+        if T > eng.max_T:
+            raise cabi.LadeHipError(f"step of {T} tokens exceeds the engine's max_T={eng.max_T}")
+        logits = eng.forward(torch.tensor(ids, dtype=torch.int32, device=dev), torch.tensor(pos, dtype=torch.int32, device=dev),
+                             StepMask.from_levels(n_input, level_sizes, lguess, gs, past_size),
+                             torch.tensor(rows, dtype=torch.int32, device=dev), len(rows)).float()
     ret = StepOutput()
     ret.out_logits = logits[0:1]
     ret.inp_logits = logits[1:1 + window].unsqueeze(0)

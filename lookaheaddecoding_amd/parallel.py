@@ -26,7 +26,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 import torch.distributed as dist
 
-REC_HEAD = 4           # first_guess, max_hit, max_hit_idx, n_inp
+REC_HEAD = 4           # first_guess, n_inp, g_local, (reserved)
 
 
 @dataclass
@@ -61,8 +61,9 @@ def shard_level_sizes(level_lens: Sequence[int], c0: int, c1: int) -> List[int]:
     return out
 
 
-def rec_words(gs: int, wcap: int) -> int:
-    return REC_HEAD + gs + wcap
+def rec_words(gs: int, wcap: int, G: int = 0) -> int:
+    """int32 words of one rank's record: head | new window tokens [wcap] | argmax ids of its candidate rows [<= G*gs]"""
+    return REC_HEAD + wcap + max(G, 0) * gs
 
 
 class HipLPBackend:
@@ -73,10 +74,10 @@ class HipLPBackend:
         from .cabi import call, ptr
         self.dec, self.ops, self.call, self.ptr = dec, ops, call, ptr
         st = dec.st
-        self.rw = rec_words(dec.gs, st.wcap)
+        self.rw = rec_words(dec.gs, st.wcap, dec.G)
         dev = dec.e.device
         self.rec = torch.zeros(self.rw, dtype=torch.int32, device=dev)
-        self.scratch = torch.zeros(max(st.wcap, dec.W) * 2 + 64, dtype=torch.int32, device=dev)
+        self.scratch = torch.zeros(dec.lp.R * st.wcap + dec.G * dec.gs + 64, dtype=torch.int32, device=dev)
         self.device = dev
 
     def begin(self, prompt: Sequence[int], window0: Sequence[int], eos: int) -> None:
@@ -99,23 +100,10 @@ class HipLPBackend:
         g_local = ghi - glo
         cand_rows = g_local * gs if phase == 2 else 0
         if phase == 0:
+            # rank r prefills the prompt + the L0 prefix up to its last column (lade/decoding.py:981-984)
             ids_h = self.prompt + self.window0[: c1 - 1]
-            total = len(ids_h)
-            n_win = c1 - 1
-            last_len = min(total, max(e.max_T, n_win + 1))
-            done = 0
-            while total - done > last_len:
-                n = min(e.max_T, total - last_len - done)
-                st.ids[:n].copy_(torch.tensor(ids_h[done:done + n], dtype=torch.int32))
-                st.pos[:n].copy_(torch.arange(done, done + n, dtype=torch.int32))
-                e.forward(st.ids, st.pos, StepMask(T=n, P=done, is_prefill=True), st.sel, 0)
-                done += n
-            T = total - done
-            st.ids[:T].copy_(torch.tensor(ids_h[done:], dtype=torch.int32))
-            st.pos[:T].copy_(torch.arange(done, total, dtype=torch.int32))
-            mask = StepMask(T=T, P=done, is_prefill=True)
-            n_inp = n_win
-            out_row = len(self.prompt) - done - 1
+            n_inp = c1 - 1
+            logits, done = e.prefill(ids_h, [len(self.prompt) - 1] + list(range(len(self.prompt), len(ids_h))))
         else:
             ls = shard_level_sizes(level_lens, c0, c1)
             mask = StepMask.from_levels(n_input, ls, cand_rows, gs, P)
@@ -124,14 +112,12 @@ class HipLPBackend:
             call("lade_build_inputs", None, None, n_input, ptr(st.window), st.wcap, ptr(st.ctl), len(level_lens) - 1, c0, c1,
                  guess_ptr, g_local if phase == 2 else 0, gs, cand_rows, ptr(st.ids), ptr(st.pos), None)
             n_inp = ls[-1]
-            out_row = n_input - 1
-        rows = [out_row] + list(range(T - cand_rows - n_inp, T - cand_rows)) + list(range(T - cand_rows, T))
-        st.sel[:len(rows)].copy_(torch.tensor(rows, dtype=torch.int32))
-        logits = e.forward(st.ids, st.pos, mask, st.sel, len(rows))
+            rows = [n_input - 1] + list(range(T - cand_rows - n_inp, T - cand_rows)) + list(range(T - cand_rows, T))
+            st.sel[:len(rows)].copy_(torch.tensor(rows, dtype=torch.int32))
+            logits = e.forward(st.ids, st.pos, mask, st.sel, len(rows))
         self.ops.argmax_rows(logits, out=st.am)
         am = st.am.data_ptr()
-        guess_ptr = st.guess.data_ptr() + 4 * glo * gs
-        call("lade_lp_pack", am, am + 4, n_inp, guess_ptr, am + 4 * (1 + n_inp), g_local if phase == 2 else 0, gs, st.wcap, ptr(self.rec), self.rw)
+        call("lade_lp_pack", am, am + 4, n_inp, am + 4 * (1 + n_inp), g_local if phase == 2 else 0, gs, st.wcap, ptr(self.rec), self.rw)
         return self.rec
 
     def apply(self, all_rec: torch.Tensor, R: int, phase: int) -> List[int]:
@@ -147,7 +133,20 @@ class HipLPBackend:
     def broadcast_window(self, window0: List[int], lp: LPContext) -> List[int]:
         t = torch.tensor(window0, dtype=torch.int32, device=self.device)
         dist.broadcast(t, src=0, group=lp.group)
+        self.sync_gemm_choice(lp)
         return t.tolist()
+
+    def sync_gemm_choice(self, lp: LPContext) -> None:
+        """Once per process group: rank 0's autotuned GEMM table is adopted by every rank (each process would otherwise time
+        its own candidates and could settle on kernels that round 16-bit results differently)."""
+        e = self.dec.e
+        if getattr(e, "_lp_gemm_synced", False) or not e.custom_gemm or not (dist.is_available() and dist.is_initialized()):
+            return
+        box = [e.tune_all() if lp.rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=lp.group)
+        if lp.rank != 0:
+            e.adopt_gemm_cfg(box[0])
+        e._lp_gemm_synced = True
 
 
 class LPRunner:

@@ -13,7 +13,7 @@ class OracleLPBackend:
         self.model, self.W, self.N, self.G, self.gs = model, W, N, G, N - 1
         self.pool_from_prompt = bool(pool_from_prompt)
         self.wcap = W + N - 3
-        self.rw = rec_words(self.gs, self.wcap)
+        self.rw = rec_words(self.gs, self.wcap, G)
 
     def begin(self, prompt, window0, eos):
         self.cache = self.model.new_cache()
@@ -42,11 +42,12 @@ class OracleLPBackend:
         self.kvcache_len = out.kvcache_len
         fg = int(torch.argmax(out.out_logits).item())
         inp = torch.argmax(out.inp_logits, dim=-1).tolist()
-        mh, mi, hits = O.greedy_verify(fg, guess, torch.argmax(out.guess_logits, dim=-1).tolist() if guess else [], gs)
+        am_guess = torch.argmax(out.guess_logits, dim=-1).tolist() if guess else []
         rec = torch.zeros(self.rw, dtype=torch.int32)
-        rec[0], rec[1], rec[2], rec[3] = fg, mh, mi, len(inp)
-        rec[REC_HEAD:REC_HEAD + gs] = torch.tensor(hits, dtype=torch.int32)
-        rec[REC_HEAD + gs:REC_HEAD + gs + len(inp)] = torch.tensor(inp, dtype=torch.int32)
+        rec[0], rec[1], rec[2] = fg, len(inp), len(am_guess) // gs
+        rec[REC_HEAD:REC_HEAD + len(inp)] = torch.tensor(inp, dtype=torch.int32)
+        if am_guess:
+            rec[REC_HEAD + self.wcap:REC_HEAD + self.wcap + len(am_guess)] = torch.tensor(am_guess, dtype=torch.int32)
         self.last_ids = out.layout.ids
         return rec
 
@@ -56,14 +57,18 @@ class OracleLPBackend:
         fg = recs[0][0]
         toks = []
         for r in (range(R - 1, R) if phase == 0 else range(R)):
-            n = recs[r][3]
-            toks += recs[r][REC_HEAD + gs:REC_HEAD + gs + n]
-        max_hit, win = 0, 0
-        if phase == 2:
+            n = recs[r][1]
+            toks += recs[r][REC_HEAD:REC_HEAD + n]
+        # verification on the gathered argmax rows against rank 0's first token (lade/decoding.py:1024, :1071-1096)
+        max_hit, win, hits = 0, 0, [fg] + [0] * (gs - 1)
+        if phase == 2 and self.guess_all:
+            am_all = []
             for r in range(R):
-                if recs[r][1] > max_hit:
-                    max_hit, win = recs[r][1], r
-        hits = recs[win][REC_HEAD:REC_HEAD + gs] if max_hit > 0 else [fg] + [0] * (gs - 1)
+                am_all += recs[r][REC_HEAD + self.wcap:REC_HEAD + self.wcap + recs[r][2] * gs]
+            max_hit, idx, hits = O.greedy_verify(fg, self.guess_all, am_all, gs)
+            cnt = (len(self.guess_all) // gs + R - 1) // R
+            win = idx // cnt if max_hit > 0 else 0
+            hits = list(hits) + [0] * (gs - len(hits))
         if phase == 2:
             O.update_token_map(self.token_map, self.lst_token, self.past, toks, N, W, G)
             O.window_roll(self.past, toks, N)
