@@ -398,19 +398,21 @@ class StepEngine:
     @_on_device
     def plain_greedy(self, prompt: Sequence[int], max_length: int, eos_token_id: Optional[int] = None) -> List[int]:
         self.reset()
-        ids = list(prompt)
-        feed = list(prompt)
-        P = 0
-        while len(ids) < max_length:
-            T = len(feed)
-            t_ids = torch.tensor(feed, dtype=torch.int32, device=self.device)
-            t_pos = torch.arange(P, P + T, dtype=torch.int32, device=self.device)
-            sel = torch.tensor([T - 1], dtype=torch.int32, device=self.device)
-            logits = self.forward(t_ids, t_pos, StepMask(T=T, P=P, is_prefill=True), sel, 1)
+        ids = [int(t) for t in prompt]
+        if len(ids) >= max_length:
+            return ids
+        logits, _ = self.prefill(ids, [len(ids) - 1])                # long prompts: causal chunks of <= max_T tokens
+        P = len(ids)
+        one_id = torch.zeros(1, dtype=torch.int32, device=self.device)
+        one_pos = torch.zeros(1, dtype=torch.int32, device=self.device)
+        sel = torch.zeros(1, dtype=torch.int32, device=self.device)
+        while True:
             nxt = int(ops.argmax_rows(logits)[0].item())
             ids.append(nxt)
-            P += T
-            feed = [nxt]
-            if eos_token_id is not None and nxt == eos_token_id:
+            if len(ids) >= max_length or (eos_token_id is not None and nxt == eos_token_id):
                 break
+            one_id.fill_(nxt)
+            one_pos.fill_(P)
+            logits = self.forward(one_id, one_pos, StepMask(T=1, P=P, is_prefill=True), sel, 1)
+            P += 1
         return ids

@@ -288,15 +288,15 @@ def test_full_width_real_weights_bf16_cold(shape, layers, W, N, G):
 
 @pytest.mark.parametrize("shape,layers,W,N,G", FULL_WIDTH)
 def test_full_width_real_weights_bf16_with_accepted_ngrams(shape, layers, W, N, G):
-    """The accept path with live attention / MLP at the BASELINE widths: tied embeddings of larger scale (std 0.25) make the
-    model copy-biased, so its greedy stream becomes periodic and the pool hits (S > 2), while every projection still feeds
-    the residual stream.  Lookahead == plain greedy on the same engine, every token within the oracle margin, and the cache
+    """The accept path with live attention / MLP at the BASELINE widths: tied embeddings of larger scale (std 1.0, the same
+    order as a layer's contribution to the residual stream) make the model copy-biased, so its greedy stream becomes
+    periodic and the pool hits (S > 2), while every projection still feeds the residual stream.  Lookahead == plain greedy on the same engine, every token within the oracle margin, and the cache
     after the run (rows committed out of candidate rows) equals a plain causal prefill of the same tokens."""
     from lookaheaddecoding_amd.decoding import LookaheadDecoder
     from lookaheaddecoding_amd.engine import StepEngine
     cfg = make_config(shape, layers=layers)
     w = random_weights_torch(cfg, seed=0, dtype=torch.bfloat16, device="cuda")
-    w["embed"] = (w["embed"].float() * (0.25 / 0.02)).bfloat16()
+    w["embed"] = (w["embed"].float() * (1.0 / 0.02)).bfloat16()
     w["lm_head"] = w["embed"]
     w_cpu = {k: v.float().cpu() for k, v in w.items()}
     eng = StepEngine(cfg, w, dtype=torch.bfloat16, device="cuda", max_seq=1024, max_T=512)

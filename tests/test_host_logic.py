@@ -1,0 +1,77 @@
+"""CPU: host-side logic that needs no GPU - RoPE tables (default / linear / llama3 scaling) against HuggingFace's own rotary
+embedding, and the guards of the HF drop-in (config_from_hf refuses what the HIP step does not implement; the reference
+itself only patches the Llama classes, lade/utils.py:40-56)."""
+import pytest
+import torch
+
+
+def _hf_cos_sin(rope_parameters, d, n_pos, max_pos=4096):
+    from transformers import LlamaConfig
+    from transformers.models.llama.modeling_llama import LlamaRotaryEmbedding
+    cfg = LlamaConfig(hidden_size=d * 2, num_attention_heads=2, num_hidden_layers=1, intermediate_size=32, vocab_size=32,
+                      max_position_embeddings=max_pos, rope_parameters=rope_parameters)
+    rot = LlamaRotaryEmbedding(cfg)
+    pos = torch.arange(n_pos)[None]
+    cos, sin = rot(torch.zeros(1, n_pos, d), pos)
+    return cos[0], sin[0]
+
+
+@pytest.mark.parametrize("scaling", [None,
+                                     {"rope_type": "linear", "factor": 4.0},
+                                     {"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+                                      "original_max_position_embeddings": 512}])
+def test_rope_tables_match_huggingface(scaling):
+    from lookaheaddecoding_amd.engine import rope_tables
+    d, n_pos, theta = 64, 1500, 10000.0
+    rp = {"rope_type": "default", "rope_theta": theta} if scaling is None else dict(scaling, rope_theta=theta)
+    cos_ref, sin_ref = _hf_cos_sin(rp, d, n_pos)
+    cos, sin = rope_tables(d, n_pos, theta, torch.float32, "cpu", scaling)
+    assert torch.allclose(cos, cos_ref, atol=2e-5) and torch.allclose(sin, sin_ref, atol=2e-5)
+    if scaling is not None:            # the scaling really changes the table
+        c0, _ = rope_tables(d, n_pos, theta, torch.float32, "cpu", None)
+        assert not torch.allclose(c0, cos, atol=1e-3)
+
+
+def test_unknown_rope_scaling_is_refused():
+    from lookaheaddecoding_amd import cabi
+    from lookaheaddecoding_amd.engine import rope_tables
+    with pytest.raises(cabi.LadeHipError):
+        rope_tables(64, 128, 10000.0, torch.float32, "cpu", {"rope_type": "yarn", "factor": 2.0})
+    with pytest.raises(cabi.LadeHipError):
+        rope_tables(64, 128, 10000.0, torch.float32, "cpu", {"rope_type": "dynamic", "factor": 2.0})
+
+
+def test_config_from_hf_guards():
+    from transformers import LlamaConfig, LlamaForCausalLM, MistralConfig, MistralForCausalLM
+    from lookaheaddecoding_amd import cabi, hf
+    small = dict(vocab_size=64, hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=1)
+    m = LlamaForCausalLM(LlamaConfig(**small, max_position_embeddings=256))
+    c = hf.config_from_hf(m)
+    assert c["heads"] == 2 and c["kv_heads"] == 1 and c["head_dim"] == 16 and c["rope_scaling"] is None and c["rope_theta"] == 10000.0
+    m3 = LlamaForCausalLM(LlamaConfig(**small, max_position_embeddings=256,
+                                      rope_parameters={"rope_type": "llama3", "rope_theta": 500000.0, "factor": 8.0, "low_freq_factor": 1.0,
+                                                       "high_freq_factor": 4.0, "original_max_position_embeddings": 128}))
+    c3 = hf.config_from_hf(m3)
+    assert c3["rope_scaling"]["rope_type"] == "llama3" and c3["rope_theta"] == 500000.0
+    with pytest.raises(cabi.LadeHipError):       # another architecture: Llama math would silently produce wrong tokens
+        hf.config_from_hf(MistralForCausalLM(MistralConfig(**small, max_position_embeddings=256, sliding_window=None)))
+    my = LlamaForCausalLM(LlamaConfig(**small, max_position_embeddings=256,
+                                      rope_parameters={"rope_type": "yarn", "rope_theta": 10000.0, "factor": 2.0, "original_max_position_embeddings": 128}))
+    with pytest.raises(cabi.LadeHipError):
+        hf.config_from_hf(my)
+    mb = LlamaForCausalLM(LlamaConfig(**small, max_position_embeddings=256, attention_bias=True))
+    with pytest.raises(cabi.LadeHipError):
+        hf.config_from_hf(mb)
+
+
+def test_engine_refuses_cpu_and_missing_library(monkeypatch):
+    """the product path has no CPU fallback: without a GPU the engine does not construct"""
+    from lookaheaddecoding_amd import cabi
+    from lookaheaddecoding_amd.engine import StepEngine
+    from lookaheaddecoding_amd.weights import make_config, random_weights_numpy
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    cfg = make_config("tiny-d16")
+    w = {k: torch.as_tensor(v) for k, v in random_weights_numpy(cfg).items()}
+    with pytest.raises(cabi.LadeHipError):
+        StepEngine(cfg, w, dtype=torch.float32, device="cuda")
