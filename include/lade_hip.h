@@ -32,7 +32,9 @@
  *   lade_lp_pack / lade_lp_reduce_apply   the per-step lookahead-parallel exchange record
  *                            lade/decoding.py:1023-1024, 1088-1107 (four pickled object collectives
  *                            -> one fixed int32 all-gather issued by the host through RCCL)
- *   lade_softmax_rows        fp32 probabilities of the sampling verify (temperature applied)  lade/decoding.py:484-489
+ *   lade_softmax_rows / lade_softmax_gather   probabilities of the sampling verify: one full row (the distribution a token is
+ *                            finally drawn from) / the per-candidate draft probabilities of the acceptance loop, gathered on
+ *                            the device without materialising guess_probs   lade/decoding.py:484-540
  *   lade_rmsnorm / lade_add_rmsnorm / lade_silu_mul / lade_gather_rows   LlamaRMSNorm (+ residual add), SwiGLU,
  *                            embedding / logits-row gather around the GEMMs
  *                            lade/models/modeling_llama.py:222-227, :360-380, :1164 ("next" row)
@@ -239,6 +241,16 @@ int lade_lp_reduce_apply(const int32_t* all_rec, int32_t R, int32_t rec_words, i
 /* probs[r][:] = softmax(logits[r][:] / temperature) in fp32 */
 int lade_softmax_rows(const void* logits, int64_t ld, int32_t rows, int32_t V, int32_t dtype, float temperature,
                       float* probs, void* stream);
+/* Device side of the sampling verify (lade/decoding.py:484-540; K11 of SURVEY 8b).  logits: [..][ld] with logical row 0 = the
+ * out row (physical row 0) and logical row 1 + c*gs + j = position j of candidate c (physical row 1 + c*gs + j + skip: the step's
+ * logits hold the `skip` window rows between the out row and the candidate rows); padded candidate slots are ignored.  Per row the
+ * softmax statistics of logits/temperature go to stats[row] = {max, sum of exponentials}; the probabilities the acceptance
+ * loop consults are gathered into scal[row][g_cap]: row 0 -> P(first token of candidate c), row 1 + c'*gs + j (j < gs-1) ->
+ * P(token j+1 of candidate c | the prefix candidate c' shares up to j).  guess: the candidates' tokens [g][gs] (device);
+ * g is read from *g_dev when that is not null (hipGraph steps), capped by g_cap.  Nothing of size [rows][V] is written. */
+int lade_softmax_gather(const void* logits, int64_t ld, int32_t rows, int32_t V, int32_t dtype, float temperature, int32_t skip,
+                        const int32_t* guess, const int32_t* g_dev, int32_t g, int32_t gs, int32_t g_cap, float* scal,
+                        float* stats, void* stream);
 
 /* ---- glue around the GEMMs -------------------------------------------------------------- */
 /* y = weight * (x * rsqrt(mean(x^2) + eps)) with the reference's rounding (fp32 norm, cast, then * weight) */

@@ -71,6 +71,7 @@ SIGNATURES = {
     "lade_lp_pack": [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp],
     "lade_lp_reduce_apply": [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp],
     "lade_softmax_rows": [_vp, _i64, _i32, _i32, _i32, _f32, _vp, _vp],
+    "lade_softmax_gather": [_vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "lade_rmsnorm": [_vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp],
     "lade_add_rmsnorm": [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp],
     "lade_silu_mul": [_vp, _vp, _i32, _i32, _i32, _vp],

@@ -31,7 +31,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int KT = 64;        // keys per tile
-constexpr int ROWS_PER_WG = 128;
 constexpr float NEG_BIG = -1.0e30f;     // initial running max
 constexpr float MASKED = -3.0e30f;      // masked score: 2^(MASKED - m) == 0 even while m is still NEG_BIG
 
@@ -160,12 +159,7 @@ template <> struct Mfma<F16> {
     }
 };
 
-#ifndef LADE_ATTN_NSTAGE
-#define LADE_ATTN_NSTAGE 3
-#endif
-constexpr int NSTAGE = LADE_ATTN_NSTAGE;   // LDS ring depth: a work-group's first NSTAGE tiles are requested at once
 constexpr float RESCALE_THR = 8.0f;    // log2 units: the running max is only raised when it grows by more
-constexpr int NTHREADS = 512;          // 8 waves: 4 row groups x 2 key halves, two waves per SIMD
 
 // optional in-kernel timeline (build with -DLADE_ATTN_TIMELINE, run with LADE_ATTN_DBG=16): thread 0 of every
 // work-group stamps s_memtime at 7 points into the words that follow part_ml
@@ -189,75 +183,79 @@ __device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "mem
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// Work split inside a work-group: wave w owns query rows [32*rg, 32*rg+32) of the block and the
-// 32-key sub-tile `kh` of every 64-key tile.  rg = 2*(w>>2) + (w&1), kh = (w>>1)&1: waves w and w+4
-// share a SIMD (dispatch order 0,2,1,3,0,2,1,3), so with T <= 64 (only row groups 0,1 populated) the
-// four busy waves still sit on four different SIMDs, and with more rows every SIMD interleaves two
-// waves - one in its MFMA phase while the other waits on LDS or runs the softmax VALU work.
-// The two key halves keep separate online-softmax states and are merged through LDS at the end.
-template <typename T, int D>
-__global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(AttnK a) {
+// Work split inside a work-group of RG x KQ waves: wave (rg, kq) owns query rows [32*rg, 32*rg+32) of the block and the
+// 32-key part kq of every stage; a stage is KQ/2 tiles of 64 keys.  Three shapes are built:
+//   RG=4, KQ=2 (8 waves, 128 rows, stage = 1 tile,  3-stage ring)   steps of more than 64 (head-in-group, token) rows
+//   RG=2, KQ=4 (8 waves,  64 rows, stage = 2 tiles, 2-stage ring)   <= 64 rows: every wave computes (a steady 7B step has 60)
+//   RG=1, KQ=4 (4 waves,  32 rows, stage = 2 tiles, 2-stage ring)   <= 32 rows (lookahead-parallel ranks, TinyLlama steps)
+// rg / kq from the wave index: waves w and w+4 share a SIMD (dispatch order 0,2,1,3,0,2,1,3); with RG=4 and T <= 64 rows the
+// four busy waves sit on four different SIMDs, and with more rows every SIMD interleaves two waves - one in its MFMA phase
+// while the other waits on LDS or runs the softmax VALU work.
+// KV split sp of n_splits takes the 64-key tiles sp, sp+n_splits, sp+2*n_splits, ...: the splits differ by at most one tile
+// whatever the cache length is.  The KQ key parts keep separate online-softmax states and are merged through LDS at the end.
+template <typename T, int D, int RG, int KQ>
+__global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
+    constexpr int NW = RG * KQ;                    // waves
+    constexpr int NTHR = 64 * NW;
+    constexpr int TPS = KQ / 2;                    // 64-key tiles per stage
+    constexpr int NSTG = TPS == 1 ? 3 : 2;         // ring depth (a work-group's first NSTG stages are requested at once)
+    constexpr int ROWS = 32 * RG;
     constexpr int KSTEPS = D / 16;                 // MFMA k-steps of S^T
     constexpr int DBLK = D / 32;                   // 32-row blocks of O^T
-    constexpr int K_BYTES = KT * D * 2, V_BYTES = D * KT * 2, STAGE_BYTES = K_BYTES + V_BYTES;
-    constexpr int Q_BYTES = ROWS_PER_WG * D * 2;
-    constexpr int K_PIECES = K_BYTES / 1024 / 8;   // 1-KiB DMA pieces per wave per tile
-    constexpr int V_PIECES = V_BYTES / 1024 / 8;
-    constexpr int Q_PIECES = Q_BYTES / 1024 / 8;
-    constexpr int PIECES = K_PIECES + V_PIECES;
+    constexpr int K_BYTES = KT * D * 2, V_BYTES = D * KT * 2, TILE_BYTES = K_BYTES + V_BYTES, STAGE_BYTES = TPS * TILE_BYTES;
+    constexpr int Q_BYTES = ROWS * D * 2;
+    constexpr int KPW = K_BYTES / 1024 / NW;       // 1-KiB DMA pieces per wave per tile
+    constexpr int VPW = V_BYTES / 1024 / NW;
+    constexpr int QPW = Q_BYTES / 1024 / NW;
+    constexpr int PIECES = TPS * (KPW + VPW);      // per wave per stage
     constexpr int K_CPR = D / 8;                   // 16-B chunks per K (and Q) row
+    static_assert(KPW >= 1 && VPW >= 1 && QPW >= 1, "every wave moves at least one piece of every tile");
 
-    // LDS: [ring of NSTAGE (K tile | V^T tile)] [Q tile]; the ring is reused for the merge + store staging
+    // LDS: [ring of NSTG stages of TPS x (K tile | V^T tile)] [Q tile]; the ring is reused for the merge + store staging
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* q_lds = smem + NSTAGE * STAGE_BYTES;
+    unsigned char* q_lds = smem + NSTG * STAGE_BYTES;
     dbg_stamp(a, 0);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rg = ((wave >> 2) << 1) | (wave & 1), kh = (wave >> 1) & 1;
+    int rg, kq;
+    if (RG == 4) { rg = ((wave >> 2) << 1) | (wave & 1); kq = (wave >> 1) & 1; }
+    else if (RG == 2) { rg = wave & 1; kq = wave >> 1; }
+    else { rg = 0; kq = wave; }
+    const int ts_mine = kq >> 1, kh = kq & 1;      // this wave's tile within the stage, and its 32-key half of that tile
     const int ql = lane & 31, hi = lane >> 5;
     const int kvh = blockIdx.y, sp = blockIdx.z;
     const int n_rep = a.H / a.Hkv;
-
-    lade_mask_params m = a.m;
-    if (a.dyn_P) m.P = *a.dyn_P;
-    const int S_tot = m.P + m.T;
-    const int n_tiles = (S_tot + KT - 1) / KT;
-    const int tps = (n_tiles + a.n_splits - 1) / a.n_splits;
-    const int tile0 = sp * tps;
-    const int nt = max(0, min(tile0 + tps, n_tiles) - tile0);
-    const int n_rows = n_rep * m.T;
-    const float invT = 1.0f / (float)m.T;
-    // row r of the (head-in-group, token) row space -> (hg, t); exact for r < 4096, T <= 512
-    auto split_row = [&](int r, int& hg, int& t) {
-        if (n_rep == 1) { hg = 0; t = r; }
-        else { hg = (int)(((float)r + 0.5f) * invT); t = r - hg * m.T; }
-    };
+    const int ns = a.n_splits;
 
     const uint16_t* kbase = a.k + (size_t)kvh * a.S_max * D;
     const uint16_t* vbase = a.vt + (size_t)kvh * D * a.S_max;
 
-    // ---- LDS-DMA: Q tile once, then K / V^T tiles; every wave moves its share of 1-KiB pieces ----
-#pragma unroll
-    for (int i = 0; i < Q_PIECES; ++i) {
-        const int piece = wave * Q_PIECES + i;
-        const int row = piece * (64 / K_CPR) + lane / K_CPR;
-        const int c = (lane % K_CPR) ^ swz16<2 * D>(row);
-        int r = blockIdx.x * ROWS_PER_WG + row, hg, t;
-        if (r >= n_rows) r = 0;                       // rows past the end read row 0; never stored
-        split_row(r, hg, t);
-        const uint16_t* src = a.q + (size_t)t * a.q_row_stride + (size_t)(kvh * n_rep + hg) * D + c * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(q_lds + piece * 1024), 16, 0, 0);
+    // ---- split geometry: split sp covers the 64-key tiles base, base+stride, ... (my_tiles of them)
+    lade_mask_params m = a.m;
+    if (a.dyn_P) m.P = *a.dyn_P;
+    const int S_tot = m.P + m.T;
+    const int n_tiles = (S_tot + KT - 1) / KT;
+    int base, stride, my_tiles;
+    if (a.dbg & 64) {                               // interleaved: splits differ by at most one tile
+        base = sp; stride = ns;
+        my_tiles = sp < n_tiles ? (n_tiles - sp + ns - 1) / ns : 0;
+    } else {                                        // contiguous key ranges
+        const int tps = (n_tiles + ns - 1) / ns;
+        base = sp * tps; stride = 1;
+        my_tiles = max(0, min(base + tps, n_tiles) - base);
     }
-    auto issue_tile = [&](int tile, int stage) {
-        const int k0 = tile * KT;
-        unsigned char* ks = smem + stage * STAGE_BYTES;
+    // ---- LDS-DMA (no VGPR staging): the split's first NSTG stages are requested before the row bookkeeping; a tile that lies
+    // beyond the split is a harmless read inside the cache allocation (an L2 hit of the split's first tile) and is never computed on
+    const int last_tile = a.S_max / KT - 1;
+    auto issue_tiles = [&](int stage, int ts, int tile) {
+        const int k0 = min(tile, last_tile) * KT;
+        unsigned char* ks = smem + stage * STAGE_BYTES + ts * TILE_BYTES;
         unsigned char* vs = ks + K_BYTES;
 #pragma unroll
-        for (int i = 0; i < K_PIECES; ++i) {
-            const int piece = wave * K_PIECES + i;
+        for (int i = 0; i < KPW; ++i) {
+            const int piece = wave * KPW + i;
             const int row = piece * (64 / K_CPR) + lane / K_CPR;
             const int c = (lane % K_CPR) ^ swz16<2 * D>(row);
             const uint16_t* src = kbase + (size_t)(k0 + row) * D + c * 8;
@@ -265,8 +263,8 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(AttnK a) {
                                              (__attribute__((address_space(3))) void*)(ks + piece * 1024), 16, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < V_PIECES; ++i) {
-            const int piece = wave * V_PIECES + i;
+        for (int i = 0; i < VPW; ++i) {
+            const int piece = wave * VPW + i;
             const int row = piece * 8 + (lane >> 3);
             const int c = (lane & 7) ^ swz16<2 * KT>(row);
             const uint16_t* src = vbase + (size_t)row * a.S_max + k0 + c * 8;
@@ -275,12 +273,46 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(AttnK a) {
         }
     };
 #pragma unroll
-    for (int s = 0; s < NSTAGE; ++s)
-        if (s < nt) issue_tile(tile0 + s, s);
+    for (int ts = 0; ts < TPS; ++ts) issue_tiles(0, ts, ts < my_tiles ? base + ts * stride : base);
+
+    const int n_rows = n_rep * m.T;
+    const float invT = 1.0f / (float)m.T;
+    // row r of the (head-in-group, token) row space -> (hg, t); exact for r < 4096, T <= 512
+    auto split_row = [&](int r, int& hg, int& t) {
+        if (n_rep == 1) { hg = 0; t = r; }
+        else { hg = (int)(((float)r + 0.5f) * invT); t = r - hg * m.T; }
+    };
+    // the Q tile goes between stage 0 and the younger stages: the first counted wait covers exactly stage 0 + Q
+#pragma unroll
+    for (int i = 0; i < QPW; ++i) {
+        const int piece = wave * QPW + i;
+        const int row = piece * (64 / K_CPR) + lane / K_CPR;
+        const int c = (lane % K_CPR) ^ swz16<2 * D>(row);
+        int r = blockIdx.x * ROWS + row, hg, t;
+        if (r >= n_rows) r = 0;                       // rows past the end read row 0; never stored
+        split_row(r, hg, t);
+        const uint16_t* src = a.q + (size_t)t * a.q_row_stride + (size_t)(kvh * n_rep + hg) * D + c * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(q_lds + piece * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int s = 1; s < NSTG; ++s)
+#pragma unroll
+        for (int ts = 0; ts < TPS; ++ts) issue_tiles(s, ts, s * TPS + ts < my_tiles ? base + (s * TPS + ts) * stride : base);
     dbg_stamp(a, 1);
 
+    const int nt = (my_tiles + TPS - 1) / TPS;                                  // stages
+    const int nt_issued = max(nt, NSTG);                                        // the first NSTG stages are always in flight
+    // global index (64-key units) of tile ts of stage j; a stage's missing second tile re-reads the split's first tile (an L2
+    // hit) so that every stage carries the same number of pieces for the counted vmcnt waits - it is never computed on
+    auto tile_of = [&](int j, int ts) { const int q = j * TPS + ts; return q < my_tiles ? base + q * stride : base; };
+    auto issue_stage = [&](int j, int stage) {
+#pragma unroll
+        for (int ts = 0; ts < TPS; ++ts) issue_tiles(stage, ts, tile_of(j, ts));
+    };
+
     // this lane's query row (overlaps the DMA flight)
-    const int r = blockIdx.x * ROWS_PER_WG + rg * 32 + ql;
+    const int r = blockIdx.x * ROWS + rg * 32 + ql;
     const bool valid = r < n_rows;
     int hg = 0, t = 0;
     if (valid) split_row(r, hg, t);
@@ -298,14 +330,12 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(AttnK a) {
     const int krow = 32 * kh + kappa(ql);          // LDS row (key within the tile) of this lane's MFMA row
 
     for (int i = 0; i < nt; ++i) {
-        const int stage = i % NSTAGE;
-        const unsigned char* ks = smem + stage * STAGE_BYTES;
+        const int stage = i % NSTG;
+        const unsigned char* ks = smem + stage * STAGE_BYTES + ts_mine * TILE_BYTES;
         const unsigned char* vs = ks + K_BYTES;
-        // wait for tile i (and, the first time, the older Q pieces): the pieces of the (up to 2) younger
-        // tiles stay in flight
-        const int younger = min(nt, i + NSTAGE) - (i + 1);
-        if (NSTAGE > 3 && younger >= 3) wait_vm<3 * PIECES>();
-        else if (younger >= 2) wait_vm<2 * PIECES>();
+        // wait for stage i (and, the first time, the older Q pieces): the pieces of the younger stages stay in flight
+        const int younger = min(nt_issued, i + NSTG) - (i + 1);
+        if (younger >= 2) wait_vm<2 * PIECES>();
         else if (younger == 1) wait_vm<PIECES>();
         else wait_vm<0>();
         wg_barrier();
@@ -317,24 +347,29 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(AttnK a) {
                 qf[kk] = *reinterpret_cast<const u32x4*>(q_lds + tile_off<2 * D>(rg * 32 + ql, kk * 2 + hi));
         }
 
-        const int k0 = (tile0 + i) * KT;
-        if (k0 + KT > S_tot) {
-            // last tile: V^T columns of keys >= P+T hold stale bytes; zero them (0 * NaN would poison O)
-            unsigned char* vw = smem + stage * STAGE_BYTES + K_BYTES;
-            const int first = S_tot - k0;
-            for (int idx = tid; idx < D * (KT - first); idx += NTHREADS) {
-                const int row = idx / (KT - first), key = first + idx % (KT - first);
-                *reinterpret_cast<uint16_t*>(vw + tile_off<2 * KT>(row, key >> 3) + (key & 7) * 2) = 0;
+#pragma unroll
+        for (int ts = 0; ts < TPS; ++ts) {
+            const int kt0 = tile_of(i, ts) * KT;
+            if (i * TPS + ts < my_tiles && kt0 + KT > S_tot) {          // work-group uniform
+                // last tile: V^T columns of keys >= P+T hold stale bytes; zero them (0 * NaN would poison O)
+                unsigned char* vw = smem + stage * STAGE_BYTES + ts * TILE_BYTES + K_BYTES;
+                const int first = S_tot - kt0;
+                for (int idx = tid; idx < D * (KT - first); idx += NTHR) {
+                    const int row = idx / (KT - first), key = first + idx % (KT - first);
+                    *reinterpret_cast<uint16_t*>(vw + tile_off<2 * KT>(row, key >> 3) + (key & 7) * 2) = 0;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wg_barrier();
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            wg_barrier();
         }
+        const bool have_tile = i * TPS + ts_mine < my_tiles;           // wave uniform
+        const int k0 = tile_of(i, ts_mine) * KT;
         const bool full = (k0 + KT <= m.P);           // whole tile in the cache: every key visible
         uint32_t bits = 0xffffu;                      // visibility of this lane's 16 keys 32kh + 16hi + e
         if (!full) bits = (uint32_t)(vis_bits(k0 - m.P, rd, m) >> (32 * kh + 16 * hi)) & 0xffffu;
         else if (!valid) bits = 0u;
-        if (wave_rows && __builtin_amdgcn_ballot_w64(bits != 0u) != 0ull) {
-            // ---- S^T = K Q^T on this wave's 32-key sub-tile ----
+        if (have_tile && wave_rows && __builtin_amdgcn_ballot_w64(bits != 0u) != 0ull) {
+            // ---- S^T = K Q^T on this wave's 32-key part ----
             f32x16 sacc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
@@ -401,20 +436,22 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(AttnK a) {
 #pragma unroll
             for (int db = 0; db < DBLK; ++db) oacc[db] = Mfma<T>::run(vf1[db], pf1, oacc[db]);
         }
-        if (i + NSTAGE < nt) {
+        if (i + NSTG < nt) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             wg_barrier();              // every wave is done reading this stage
-            issue_tile(tile0 + i + NSTAGE, stage);
+            issue_stage(i + NSTG, stage);
         }
     }
     dbg_stamp(a, 3);
 
-    // ---- merge the two key halves: wave (rg, 1) hands its state to wave (rg, 0), lane to lane ----
+    // ---- merge the key parts: wave (rg, kq > 0) hands its state to wave (rg, 0), lane to lane ----
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     wg_barrier();                      // ring no longer read or written: reuse it
     constexpr int EX_F4 = DBLK * 4 + 1;                // float4 slots per lane: O^T (16*DBLK floats) + (m, l, -, -)
-    float4* ex = reinterpret_cast<float4*>(smem) + (size_t)rg * EX_F4 * 64;
-    if (kh == 1) {
+    static_assert((size_t)(KQ - 1) * RG * EX_F4 * 64 * 16 <= (size_t)NSTG * STAGE_BYTES, "merge slots must fit in the ring");
+    float4* ex_all = reinterpret_cast<float4*>(smem);
+    if (kq > 0) {
+        float4* ex = ex_all + (size_t)((kq - 1) * RG + rg) * EX_F4 * 64;
 #pragma unroll
         for (int db = 0; db < DBLK; ++db)
 #pragma unroll
@@ -424,31 +461,36 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(AttnK a) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     wg_barrier();
-    if (kh == 1) return;
-    {
-        const float4 ml1 = ex[(DBLK * 4) * 64 + lane];
-        const float mm = fmaxf(m_run, ml1.x);
-        const float a0 = __builtin_amdgcn_exp2f(m_run - mm), a1 = __builtin_amdgcn_exp2f(ml1.x - mm);
-#pragma unroll
-        for (int db = 0; db < DBLK; ++db)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const float4 o1 = ex[(db * 4 + g4) * 64 + lane];
-                oacc[db][4 * g4 + 0] = oacc[db][4 * g4 + 0] * a0 + o1.x * a1;
-                oacc[db][4 * g4 + 1] = oacc[db][4 * g4 + 1] * a0 + o1.y * a1;
-                oacc[db][4 * g4 + 2] = oacc[db][4 * g4 + 2] * a0 + o1.z * a1;
-                oacc[db][4 * g4 + 3] = oacc[db][4 * g4 + 3] * a0 + o1.w * a1;
-            }
-        l_run = l_run * a0 + ml1.y * a1;
-        m_run = mm;
-    }
-
-    // ---- epilogue: normalise, transpose through LDS, store whole 2D-byte rows ----
-    dbg_stamp(a, 4);
-    l_run += __shfl_xor(l_run, 32);
     constexpr int RS = 2 * D + 16;                     // staging row stride (bytes), 16-B aligned
-    unsigned char* stg = reinterpret_cast<unsigned char*>(ex);      // this wave's exchange slot is free now
-    {
+    // staging rows of row group rg: the merge slot of (kq = 1, rg), which only wave (rg, 0) reads (LDS operations of one wave
+    // execute in order, so its staging writes cannot overtake its own merge reads); without key parts to merge, the ring head
+    unsigned char* stg_base = reinterpret_cast<unsigned char*>(ex_all);
+    constexpr size_t STG_STRIDE = (size_t)EX_F4 * 64 * 16;
+    static_assert(32 * RS <= STG_STRIDE, "a row group's staging rows fit in its merge slot");
+    if (kq == 0) {
+#pragma unroll
+        for (int pq = 1; pq < KQ; ++pq) {
+            const float4* ex = ex_all + (size_t)((pq - 1) * RG + rg) * EX_F4 * 64;
+            const float4 ml1 = ex[(DBLK * 4) * 64 + lane];
+            const float mm = fmaxf(m_run, ml1.x);
+            const float a0 = __builtin_amdgcn_exp2f(m_run - mm), a1 = __builtin_amdgcn_exp2f(ml1.x - mm);
+#pragma unroll
+            for (int db = 0; db < DBLK; ++db)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float4 o1 = ex[(db * 4 + g4) * 64 + lane];
+                    oacc[db][4 * g4 + 0] = oacc[db][4 * g4 + 0] * a0 + o1.x * a1;
+                    oacc[db][4 * g4 + 1] = oacc[db][4 * g4 + 1] * a0 + o1.y * a1;
+                    oacc[db][4 * g4 + 2] = oacc[db][4 * g4 + 2] * a0 + o1.z * a1;
+                    oacc[db][4 * g4 + 3] = oacc[db][4 * g4 + 3] * a0 + o1.w * a1;
+                }
+            l_run = l_run * a0 + ml1.y * a1;
+            m_run = mm;
+        }
+        // ---- normalise, transpose through LDS ----
+        dbg_stamp(a, 4);
+        l_run += __shfl_xor(l_run, 32);
+        unsigned char* stg = stg_base + (size_t)rg * STG_STRIDE;
         const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
 #pragma unroll
         for (int db = 0; db < DBLK; ++db)
@@ -459,26 +501,25 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(AttnK a) {
                 w[1] = pack2<T>(oacc[db][4 * g4 + 2] * inv, oacc[db][4 * g4 + 3] * inv);
                 *reinterpret_cast<u32x2*>(stg + ql * RS + (db * 32 + 8 * g4 + 4 * hi) * 2) = w;
             }
-    }
-    if (a.n_splits > 1 && valid && hi == 0) {
-        const size_t prow = ((size_t)sp * a.H + qh) * m.T + t;
-        *reinterpret_cast<float2*>(a.part_ml + prow * 2) = float2{m_run, l_run};
+        if (a.n_splits > 1 && valid && hi == 0) {
+            const size_t prow = ((size_t)sp * a.H + qh) * m.T + t;
+            *reinterpret_cast<float2*>(a.part_ml + prow * 2) = float2{m_run, l_run};
+        }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wg_barrier();
+    // ---- every wave stores whole 2D-byte rows (16 bytes per lane): the store tail is issue bound, so it is spread over all waves
     constexpr int CPR = 2 * D / 16;                    // 16-B chunks per output row
-    constexpr int RPI = 64 / CPR;                      // rows per store instruction
     uint16_t* obase = a.n_splits == 1 ? a.out : a.part_o + (size_t)sp * m.T * a.H * D;
     const int64_t ostride = a.n_splits == 1 ? a.out_row_stride : (int64_t)a.H * D;
-#pragma unroll
-    for (int it = 0; it < 32 / RPI; ++it) {
-        const int row = it * RPI + lane / CPR, c = lane % CPR;
-        const int rr = blockIdx.x * ROWS_PER_WG + rg * 32 + row;
-        if (rr < n_rows) {
-            int hg2, t2;
-            split_row(rr, hg2, t2);
-            const u32x4 v = *reinterpret_cast<const u32x4*>(stg + row * RS + c * 16);
-            *reinterpret_cast<u32x4*>(obase + (size_t)t2 * ostride + (size_t)(kvh * n_rep + hg2) * D + c * 8) = v;
-        }
+    const int row0 = blockIdx.x * ROWS;
+    const int n_store = min(ROWS, n_rows - row0) * CPR;
+    for (int idx = tid; idx < n_store; idx += NTHR) {
+        const int row = idx / CPR, c = idx % CPR;
+        int hg2, t2;
+        split_row(row0 + row, hg2, t2);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(stg_base + (size_t)(row >> 5) * STG_STRIDE + (row & 31) * RS + c * 16);
+        *reinterpret_cast<u32x4*>(obase + (size_t)t2 * ostride + (size_t)(kvh * n_rep + hg2) * D + c * 8) = v;
     }
     dbg_stamp(a, 5);
 #ifdef LADE_ATTN_TIMELINE
@@ -631,19 +672,35 @@ static AttnK make_k(const lade_attn_args* a) {
     return k;
 }
 
-template <typename T, int D>
-static int launch_fwd(const lade_attn_args* a, hipStream_t st) {
+template <typename T, int D, int RG, int KQ>
+static int launch_fwd_shape(const lade_attn_args* a, hipStream_t st) {
     const AttnK k = make_k(a);
     const int n_rep = a->H / a->Hkv;
-    dim3 grid(cdiv(n_rep * a->mask.T, ROWS_PER_WG), a->Hkv, a->n_splits);
-    const size_t lds = (size_t)KT * D * 2 * 2 * NSTAGE + (size_t)ROWS_PER_WG * D * 2;
+    constexpr int ROWS = 32 * RG, TPS = KQ / 2, NSTG = TPS == 1 ? 3 : 2;
+    dim3 grid(cdiv(n_rep * a->mask.T, ROWS), a->Hkv, a->n_splits);
+    const size_t lds = (size_t)KT * D * 2 * 2 * TPS * NSTG + (size_t)ROWS * D * 2;
     static bool attr_set = false;          // > 64 KiB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, RG, KQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((attn_fwd_kernel<T, D>), grid, dim3(NTHREADS), lds, st, k);
+    hipLaunchKernelGGL((attn_fwd_kernel<T, D, RG, KQ>), grid, dim3(64 * RG * KQ), lds, st, k);
     return check_launch("lade_attn_fwd");
+}
+
+// rows = (heads per KV head) x T of one KV head pick the work-group shape (LADE_ATTN_SHAPE = 128 | 64 | 32 forces one: experiments)
+template <typename T, int D>
+static int launch_fwd(const lade_attn_args* a, hipStream_t st) {
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("LADE_ATTN_SHAPE"); forced = e ? atoi(e) : 0; }
+    const int rows = (a->H / a->Hkv) * a->mask.T;
+    // measured (T = 60, P = 2016, 7B heads): the 64-row shape (every wave computes, three key parts to merge) is 0.4-1.0 us slower
+    // than the 128-row shape whose idle row groups only move DMA pieces, so the 128-row shape is the default for every step
+    (void)rows;
+    const int shape = forced ? forced : 128;
+    if (shape == 32) return launch_fwd_shape<T, D, 1, 4>(a, st);
+    if (shape == 64) return launch_fwd_shape<T, D, 2, 4>(a, st);
+    return launch_fwd_shape<T, D, 4, 2>(a, st);
 }
 
 }  // namespace lade
@@ -681,7 +738,9 @@ extern "C" int lade_attn_combine(const lade_attn_args* a, void* stream) {
     LADE_REQUIRE(a->dtype == LADE_BF16 || a->dtype == LADE_F16, LADE_E_DTYPE, "lade_attn_combine: dtype=%d", a->dtype);
     const AttnK k = make_k(a);
     LADE_REQUIRE(a->n_splits <= 32, LADE_E_LIMIT, "lade_attn_combine: n_splits=%d > 32", a->n_splits);
-    int hpb = 256 / (a->d / 8);                       // heads per block
+    static int hpb_env = -1;
+    if (hpb_env < 0) { const char* e = getenv("LADE_COMBINE_HPB"); hpb_env = e ? atoi(e) : 0; }
+    int hpb = hpb_env > 0 ? hpb_env : 256 / (a->d / 8);     // heads per block
     while (hpb > 1 && a->H % hpb != 0) hpb >>= 1;
     dim3 grid(a->mask.T, a->H / hpb), block(a->d / 8, hpb);
     if (a->dtype == LADE_BF16) hipLaunchKernelGGL(attn_combine_kernel<BF16>, grid, block, 0, (hipStream_t)stream, k, a->d);

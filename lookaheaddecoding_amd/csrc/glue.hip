@@ -214,6 +214,44 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const typename St<T>:
     for (int i = threadIdx.x; i < V; i += blockDim.x) out[i] *= inv;
 }
 
+// Sampling verify, device side (lade/decoding.py:484-540): the host-side acceptance loop only ever looks at the probability of a
+// DRAFT token under the distribution that follows an accepted prefix.  Row 0 is the distribution after the input token,
+// row 1 + c*gs + j the one after position j of candidate c.  For row 0 the drafts in question are the candidates' first
+// tokens, for row 1 + c*gs + j their tokens at position j+1.  One block per row: softmax statistics (max, sum of exponentials
+// of logits/temperature) in one sweep over the V logits, then the g probabilities are gathered; the [rows, V] probability
+// matrix the reference materialises (guess_probs, 15 MB per step at config 3) is never written.
+template <typename T>
+__global__ __launch_bounds__(1024) void softmax_gather_kernel(const typename St<T>::S* logits, int64_t ld, int V, float inv_temp, int skip,
+                                                              const int32_t* guess, const int32_t* g_dev, int g_host, int gs, int g_cap,
+                                                              float* scal, float* stats) {
+    __shared__ float sm[16];
+    const int row = blockIdx.x;
+    const int g = g_dev ? min(*g_dev, g_cap) : g_host;
+    int pos = 0;                                    // position inside the n-gram whose drafts this row judges
+    if (row > 0) {
+        pos = (row - 1) % gs + 1;
+        if (pos >= gs || (row - 1) / gs >= g) { pos = -1; }      // last row of a candidate / padded candidate slot: never consulted
+    }
+    const size_t base = (size_t)(row == 0 ? 0 : row + skip) * ld;
+    // online max / sum: one pass over the row
+    float mx = -INFINITY, sum = 0.f;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) {
+        const float x = ldf<T>(logits, base + i) * inv_temp;
+        if (x > mx) { sum = sum * expf(mx - x) + 1.f; mx = x; }
+        else if (x > -INFINITY) sum += expf(x - mx);
+    }
+    const float bm = block_max(mx, sm);
+    sum = (mx == -INFINITY) ? 0.f : sum * expf(mx - bm);
+    const float bs = block_sum(sum, sm);
+    if (threadIdx.x == 0) { stats[2 * row] = bm; stats[2 * row + 1] = bs; }
+    if (pos >= 0)
+        for (int c = threadIdx.x; c < g; c += blockDim.x) {
+            int tok = guess[c * gs + pos];
+            tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+            scal[(size_t)row * g_cap + c] = expf(ldf<T>(logits, base + tok) * inv_temp - bm) / bs;
+        }
+}
+
 }  // namespace lade
 
 using namespace lade;
@@ -280,6 +318,17 @@ extern "C" int lade_softmax_rows(const void* logits, int64_t ld, int32_t rows, i
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(softmax_rows_kernel<TT>, dim3(rows), dim3(256), 0, st, (const St<TT>::S*)logits, ld, V, 1.f / temperature, probs));
     return check_launch("lade_softmax_rows");
+}
+
+extern "C" int lade_softmax_gather(const void* logits, int64_t ld, int32_t rows, int32_t V, int32_t dtype, float temperature, int32_t skip,
+                                   const int32_t* guess, const int32_t* g_dev, int32_t g, int32_t gs, int32_t g_cap, float* scal,
+                                   float* stats, void* stream) {
+    LADE_REQUIRE(logits && scal && stats && rows >= 1 && V > 0 && ld >= V && temperature > 0.f && skip >= 0 && gs > 0 && g_cap >= 0 && g >= 0 && g <= g_cap &&
+                     (g_cap == 0 || guess), LADE_E_ARG, "lade_softmax_gather: rows=%d V=%d T=%f g=%d gs=%d g_cap=%d", rows, V, temperature, g, gs, g_cap);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(softmax_gather_kernel<TT>, dim3(rows), dim3(1024), 0, st, (const St<TT>::S*)logits, ld, V, 1.f / temperature, skip,
+                                             guess, g_dev, g, gs, g_cap, scal, stats));
+    return check_launch("lade_softmax_gather");
 }
 
 // split-K aware variants: the GEMM output arrives as n_parts fp32 partials [n_parts][rows][width]

@@ -305,6 +305,30 @@ class LookaheadDecoder:
 
 
     # ---- sampling ------------------------------------------------------------------------------------
+    def _sampling_buffers(self):
+        if getattr(self, "_smp", None) is None:
+            e, G, gs = self.e, max(self.G, 1), self.gs
+            rows = 1 + G * gs
+            dev = e.device
+            self._smp = dict(scal=torch.zeros(rows * G, dtype=torch.float32, device=dev), stats=torch.zeros(rows * 2, dtype=torch.float32, device=dev),
+                             scal_host=torch.zeros(rows * G, dtype=torch.float32).pin_memory(), guess_host=torch.zeros(G * gs, dtype=torch.int32).pin_memory(),
+                             probs=torch.zeros(1, e.V, dtype=torch.float32, device=dev), probs_host=torch.zeros(e.V, dtype=torch.float32).pin_memory(),
+                             am_host=torch.zeros(self.W, dtype=torch.int32).pin_memory())
+        return self._smp
+
+    def _draw(self, src: torch.Tensor, row: int, temperature: float, struck: Sequence[int], torch_gen: Optional[torch.Generator]) -> int:
+        """One token from the distribution of logits row `row` (softmax on the device) with the struck drafts removed.  A CUDA
+        generator keeps the draw on the device (what the reference does with the model on a GPU); otherwise the one row goes to
+        the host and torch.multinomial consumes the CPU generator (reproducible against the CPU-generated reference traces)."""
+        from .sampling import final_distribution
+        b = self._sampling_buffers()
+        probs = ops.softmax_rows(src[row:row + 1], temperature, out=b["probs"])[0]
+        if torch_gen is not None and torch_gen.device.type == "cuda":
+            return int(torch.multinomial(final_distribution(probs, struck), num_samples=1, generator=torch_gen).item())
+        b["probs_host"].copy_(probs, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return int(torch.multinomial(final_distribution(b["probs_host"].clone(), struck), num_samples=1, generator=torch_gen).item())
+
     @torch.no_grad()
     @_on_device
     def sample(self, prompt: Sequence[int], max_length: int, warp=None, eos_token_id: Optional[int] = None,
@@ -312,22 +336,22 @@ class LookaheadDecoder:
                on_step=None) -> GenOut:
         """`jacobi_sample_multilevel` (lade/decoding.py:137-692), single GPU (the reference has no LP here).
 
-        The model step, input assembly, pool and window stay on the GPU; what runs on the host is exactly what
-        consumes the reference's RNG streams, in the reference's order: `rng.random()` once per verification
-        trial and `torch.multinomial` (CPU generator `torch_gen`) for every sampled token (:484-540), plus the
-        `filter_window` draws (:578-580).  `warp(scores)` maps fp32 logits rows [r, V] to warped logits (the
-        Temperature / TopK / TopP warpers the reference admits, :375-377)."""
-        from .sampling import sample_verify
+        The model step, input assembly, pool and window stay on the GPU, and so do the probabilities: `lade_softmax_gather`
+        hands the host one small table of draft probabilities per step (sampling.py).  What runs on the host is exactly what
+        consumes the reference's RNG streams, in the reference's order: `rng.random()` once per verification trial,
+        one `torch.multinomial` for the token that ends the step (:484-540), and the `filter_window` draws (:578-580).
+        `warp`: a sampling.Warper (temperature / top-k / top-p; temperature alone is applied inside the kernels) or any callable
+        mapping fp32 logits rows [r, V] to warped logits (the HF warpers the reference admits, :375-377)."""
+        from .sampling import resolve_drafts
         e, st = self.e, self.st
         W, N, G, gs = self.W, self.N, self.G, self.gs
         rng = rng if rng is not None else random
-        warp = warp if warp is not None else (lambda x: x)
+        fused_T = 1.0 if warp is None else getattr(warp, "fused_temperature", None)
         self.start(prompt, eos_token_id, rng)
         all_old_tokens = list(self.prompt)
-        set_token = lambda: rng.choice(all_old_tokens)
+        buf = self._sampling_buffers()
         forced = torch.zeros(2 + cabi.MAX_LEVEL, dtype=torch.int32, device=e.device)
         override = torch.zeros(W, dtype=torch.int32, device=e.device)
-        multinomial = lambda p: int(torch.multinomial(p, num_samples=1, generator=torch_gen).item())
         trace: List[dict] = []
         while True:
             prompt_l, P, g, fill_level = self.prompt, self.P, self.g, self.fill_level
@@ -344,49 +368,60 @@ class LookaheadDecoder:
                 # steady step: input assembly + model step + argmax replayed as one hipGraph (candidate rows padded to the bucket)
                 if self._graph != "forward" or self._graph_gen != e.generation:
                     self._capture_graphs(forward_only=True)
-                phase, n_input, n_inp = 2, 1, W
+                phase, n_inp = 2, W
                 gcap = self._bucket_for(g)
                 T, cand_rows = self._graph_T[gcap], gcap * gs
                 if abs(e.n_splits_for(T, P + T) - self._graph_splits[gcap]) >= 2:
                     self._capture_graphs(forward_only=True)
                 if P + T > e.S_max:
                     raise cabi.LadeHipError(f"KV cache exhausted: P={P} + T={T} > S_max={e.S_max}")
-                mask = StepMask.from_levels(1, self._level_sizes(N - 2), cand_rows, gs, P)
                 self._graphs[gcap].replay()
                 logits = self._graph_logits[gcap]
             else:
                 phase = 2 if fill_level >= N - 2 else 1
-                n_input = 1
                 ls = self._level_sizes(fill_level)
                 cand_rows = g * gs if phase == 2 else 0
-                mask = StepMask.from_levels(n_input, ls, cand_rows, gs, P)
+                mask = StepMask.from_levels(1, ls, cand_rows, gs, P)
                 T = mask.T
-                call("lade_build_inputs", None, None, n_input, ptr(st.window), st.wcap, ptr(st.ctl), min(fill_level, N - 2), 0, -1,
+                call("lade_build_inputs", None, None, 1, ptr(st.window), st.wcap, ptr(st.ctl), min(fill_level, N - 2), 0, -1,
                      ptr(st.guess), g if phase == 2 else 0, gs, cand_rows, ptr(st.ids), ptr(st.pos), None)
                 n_inp = ls[-1]
-            if self.steps > 0 and not (self.use_graph and fill_level >= N - 2):
-                rows = [n_input - 1] + list(range(T - cand_rows - n_inp, T - cand_rows)) + list(range(T - cand_rows, T))
-                n_sel = self._set_sel(rows)
+                n_sel = self._set_sel([0] + list(range(T - cand_rows - n_inp, T - cand_rows)) + list(range(T - cand_rows, T)))
                 logits = e.forward(st.ids, st.pos, mask, st.sel, n_sel).float()    # logits.float(), modeling_llama.py:1544
                 ops.argmax_rows(logits, out=st.am)                                    # window levels are filled by argmax (:459, :545)
-            next_scores = warp(logits[0:1])
-            max_hit, max_hit_idx = 0, 0
-            if phase == 2 and g > 0:
-                guess_tokens = st.guess[:g * gs].tolist()
-                probs_next = torch.softmax(next_scores, dim=-1)[0].cpu()
-                guess_probs = torch.softmax(warp(logits[1 + n_inp:1 + n_inp + g * gs]), dim=-1)
-                hits, max_hit_idx = sample_verify(probs_next, lambda row: guess_probs[row].cpu(), guess_tokens, gs, rng, multinomial)
-                max_hit = len(hits) - 1
+            step_inputs = {}
+            if keep_trace and phase != 0:                            # what the step fed and judged (tests re-derive the probabilities)
+                step_inputs = dict(ids=st.ids[:T].tolist(), pos=st.pos[:T].tolist(), level_sizes=list(self._level_sizes(fill_level)),
+                                   cand_rows=cand_rows, g=g, drafts=st.guess[:g * gs].tolist() if phase == 2 else [])
+            # ---- the step's token(s): rejection-sampling verify over the candidates, or a plain draw (:453-540) ----
+            verify = phase == 2 and g > 0
+            rows = 1 + g * gs if verify else 1
+            if fused_T is not None:                              # temperature only: the kernels scale the logits themselves
+                src, skip, temp = logits, n_inp, fused_T
+            else:                                                # top-k / top-p / HF warper objects: warped on the device by torch
+                picked = logits[0:1] if not verify else torch.cat([logits[0:1], logits[1 + n_inp:1 + n_inp + g * gs]])
+                src, skip, temp = warp(picked), 0, 1.0
+            max_hit_idx = 0
+            if verify:
+                ops.softmax_gather(src, rows, skip, st.guess, g, gs, max(G, 1), temp, buf["scal"], buf["stats"])
+                buf["scal_host"].copy_(buf["scal"], non_blocking=True)
+                buf["guess_host"].copy_(st.guess, non_blocking=True)
+                torch.cuda.current_stream().synchronize()                      # the step's one table read-back
+                table = buf["scal_host"].view(-1, max(G, 1))[:rows].tolist()
+                if keep_trace:
+                    step_inputs["table"] = table
+                verdict = resolve_drafts(table, buf["guess_host"][:g * gs].tolist(), g, gs, rng.random)
+                hits, max_hit_idx = list(verdict.accepted), verdict.winner
+                if verdict.final_row is not None:
+                    hits.append(self._draw(src, 0 if verdict.final_row == 0 else verdict.final_row + skip, temp, verdict.struck, torch_gen))
             else:
-                probs = torch.softmax(next_scores, dim=-1)[0].cpu()
-                hits = [multinomial(probs)]
+                hits = [self._draw(src, 0, temp, (), torch_gen)]
+            max_hit = len(hits) - 1
             level_override = None
             if phase == 2 and self.eos >= 0:                                      # filter_window on the new level (:578-580)
-                new_results = st.am[1:1 + W].tolist()
-                repl = [-1] * W
-                for i, tok in enumerate(new_results):
-                    if tok == self.eos:
-                        repl[i] = set_token()
+                buf["am_host"].copy_(st.am[1:1 + W], non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                repl = [rng.choice(all_old_tokens) if tok == self.eos else -1 for tok in buf["am_host"].tolist()]
                 if any(x >= 0 for x in repl):
                     override.copy_(torch.tensor(repl, dtype=torch.int32))
                     level_override = override
@@ -406,7 +441,7 @@ class LookaheadDecoder:
             if phase != 2:
                 self.fill_level += 1
             if keep_trace:
-                trace.append(dict(T=T, P_before=P_before, max_hit=max_hit, max_hit_idx=max_hit_idx, accepted=list(accepted), phase=phase))
+                trace.append(dict(T=T, P_before=P_before, max_hit=max_hit, max_hit_idx=max_hit_idx, accepted=list(accepted), phase=phase, **step_inputs))
             if eos_hit or len(self.tokens) >= max_length:
                 break
         generated = min(len(self.tokens), max_length) - len(self.prompt)

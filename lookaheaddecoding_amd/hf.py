@@ -313,10 +313,18 @@ def jacobi_sample_multilevel(self, input_ids, logits_processor=None, stopping_cr
     for wp in warpers:
         assert type(wp) in (TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper), f"please set top_k=0.0 and top_p=1.0 {wp}"
 
-    def warp(scores):
+    if all(type(wp) is TemperatureLogitsWarper for wp in warpers):
+        # temperature only (BASELINE config 3): the scale is applied inside the device kernels (sampling.Warper.fused_temperature)
+        from .sampling import Warper
+        t = 1.0
         for wp in warpers:
-            scores = wp(input_ids, scores)
-        return scores
+            t *= float(wp.temperature)
+        warp = Warper(temperature=t)
+    else:
+        def warp(scores):
+            for wp in warpers:
+                scores = wp(input_ids, scores)
+            return scores
 
     return _run(self, input_ids, True, warp, stopping_criteria, eos_token_id, generation_config, streamer, chat)
 

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -45,19 +46,27 @@ def _dev(t: torch.Tensor, name: str):
         raise cabi.LadeHipError(f"{name} must be a GPU tensor (the HIP path has no CPU fallback)")
 
 
+def attn_block_rows(n_rep: int, T: int) -> int:
+    """query rows of one attention work-group (the kernel's shapes: 32 / 64 / 128 rows of the (head-in-group, token) space)"""
+    rows = n_rep * T
+    return 32 if rows <= 32 else (64 if rows <= 64 else 128)
+
+
 def choose_splits(H: int, n_rep: int, T: int, S_tot: int, n_cu: int = 256, allow_single: bool = True) -> int:
     """KV splits of the lookahead attention.  One CU ingests only ~55-68 GB/s from HBM (tools/hbm_probe), so the
-    grid (row blocks x KV heads x splits) should cover every CU once; a split is a whole number of 64-key
-    tiles and no split may be empty."""
-    blocks = (H // n_rep) * ((n_rep * T + 127) // 128)
+    grid (row blocks x KV heads x splits) should cover every CU once.  Split s takes the 64-key tiles s, s+n, s+2n, ...
+    (interleaved: the splits differ by at most one tile), so any count up to the tile count is balanced."""
+    br = attn_block_rows(n_rep, T)
+    blocks = (H // n_rep) * ((n_rep * T + br - 1) // br)
     tiles = max(1, (S_tot + 63) // 64)
     if tiles <= 5 and allow_single:               # <= 320 keys: one work-group per head beats a second (merge) launch
-        return 1                                  # (tools/attn_bench.py: 7.3-9.8 us vs 10.0-10.3 us at P = 64..256, T = 60)
-    # streaming time per work-group falls as tiles/splits, the merge (and the partial round trip) grows with splits:
-    # the measured optimum inside decode steps follows sqrt(tiles) - 5 splits at 18 tiles, 6 at 34, 8 at 65
-    want = max(1, min(n_cu // max(blocks, 1), math.isqrt(max(tiles - 1, 0)) + 1, tiles, 32))
-    tps = (tiles + want - 1) // want              # tiles per split
-    return (tiles + tps - 1) // tps               # drop the splits that would be empty
+        return 1
+    forced = int(os.environ.get("LADE_ATTN_SPLIT_RULE", "0"))     # experiments: 1 = fill the CUs regardless of the merge cost
+    fill = max(1, n_cu // max(blocks, 1))
+    if forced == 1:
+        return max(1, min(fill, tiles, 32))
+    # streaming time per work-group falls as tiles/splits, the merge (and the partial round trip) grows with splits
+    return max(1, min(fill, max(2, tiles // 2), tiles, 32))
 
 
 def attn_fwd(q: torch.Tensor, k_cache: torch.Tensor, vt_cache: torch.Tensor, mask: StepMask, *, H: int, Hkv: int, d: int,
@@ -192,11 +201,23 @@ def gather_rows(src: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor
     return out
 
 
-def softmax_rows(logits: torch.Tensor, temperature: float = 1.0) -> torch.Tensor:
+def softmax_rows(logits: torch.Tensor, temperature: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     assert logits.dim() == 2 and logits.stride(1) == 1
-    probs = torch.empty(logits.shape, dtype=torch.float32, device=logits.device)
+    probs = out if out is not None else torch.empty(logits.shape, dtype=torch.float32, device=logits.device)
+    assert probs.dtype == torch.float32 and probs.numel() >= logits.numel()
     call("lade_softmax_rows", ptr(logits), logits.stride(0), logits.shape[0], logits.shape[1], dtype_code(logits), float(temperature), ptr(probs))
     return probs
+
+
+def softmax_gather(logits: torch.Tensor, rows: int, skip: int, guess: torch.Tensor, g: int, gs: int, g_cap: int, temperature: float,
+                   scal: torch.Tensor, stats: torch.Tensor, g_dev: Optional[torch.Tensor] = None) -> None:
+    """Device side of the sampling verify: per-row softmax statistics + the draft probabilities the acceptance loop reads
+    (see lade_softmax_gather in include/lade_hip.h).  logits [>= rows + skip, V]; scal [rows, g_cap] fp32; stats [rows, 2] fp32."""
+    assert logits.dim() == 2 and logits.stride(1) == 1 and scal.dtype == torch.float32 and stats.dtype == torch.float32
+    V = logits.shape[1]
+    assert logits.shape[0] >= (rows + skip if rows > 1 else 1) and scal.numel() >= rows * g_cap and stats.numel() >= 2 * rows
+    call("lade_softmax_gather", ptr(logits), logits.stride(0), rows, V, dtype_code(logits), float(temperature), skip, ptr(guess), ptr(g_dev), g, gs,
+         g_cap, ptr(scal), ptr(stats))
 
 
 def gemm_skinny(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, n_split: int = 1, bn: int = 128,

@@ -75,3 +75,59 @@ def test_engine_refuses_cpu_and_missing_library(monkeypatch):
     w = {k: torch.as_tensor(v) for k, v in random_weights_numpy(cfg).items()}
     with pytest.raises(cabi.LadeHipError):
         StepEngine(cfg, w, dtype=torch.float32, device="cuda")
+
+
+def test_resolve_drafts_equals_the_oracle_verify_loop():
+    """sampling.resolve_drafts (scalars only) against the oracle's sample_verify (full probability vectors, a restatement of
+    lade/decoding.py:484-540): same accepted drafts, same winner, same distribution for the final draw, same number of
+    uniform() draws - over randomised candidate sets with shared prefixes and duplicate drafts."""
+    import random
+
+    import lade_oracle as O
+    from lookaheaddecoding_amd.sampling import final_distribution, resolve_drafts
+    rnd = random.Random(5)
+    V = 50
+    for trial in range(300):
+        gs, g = rnd.choice([2, 3, 4]), rnd.choice([1, 2, 3, 5, 8])
+        drafts = []
+        for c in range(g):
+            if c and rnd.random() < 0.5:                       # share a prefix with an earlier candidate
+                src = rnd.randrange(c)
+                keep = rnd.randrange(1, gs + 1)
+                drafts += drafts[src * gs:src * gs + keep] + [rnd.randrange(6) for _ in range(gs - keep)]
+            else:
+                drafts += [rnd.randrange(6) for _ in range(gs)]
+        gtorch = torch.Generator().manual_seed(trial)
+        sharp = rnd.choice([0.3, 1.0, 3.0])
+        probs_next = torch.softmax(torch.randn(V, generator=gtorch) * sharp + torch.nn.functional.one_hot(torch.tensor(drafts[0]), V) * 2.0, -1)
+        guess_probs = torch.softmax(torch.randn(g * gs, V, generator=gtorch) * sharp, -1)
+        for c in range(g):                                       # candidates that share a prefix see the same distributions
+            for j in range(gs):
+                for c2 in range(c):
+                    if drafts[c2 * gs:c2 * gs + j + 1] == drafts[c * gs:c * gs + j + 1]:
+                        guess_probs[c * gs + j] = guess_probs[c2 * gs + j]
+                        break
+        table = [[float(probs_next[drafts[c * gs]]) for c in range(g)]]
+        for c2 in range(g):
+            for j in range(gs):
+                table.append([float(guess_probs[c2 * gs + j][drafts[c * gs + j + 1]]) if j + 1 < gs else 0.0 for c in range(g)])
+        seed = rnd.randrange(1 << 30)
+        r1, r2 = random.Random(seed), random.Random(seed)
+        final = {}
+
+        def fake_multinomial(p):
+            final["p"] = p.clone()
+            return int(torch.argmax(p))
+
+        hits_ref, idx_ref = O.sample_verify(probs_next.clone(), guess_probs, drafts, gs, r1, fake_multinomial)
+        v = resolve_drafts(table, drafts, g, gs, r2.random)
+        assert r1.random() == r2.random(), "different number of uniform draws"
+        if v.final_row is None:
+            assert hits_ref == v.accepted and len(hits_ref) == gs
+        else:
+            assert hits_ref[:-1] == v.accepted
+            base = probs_next if v.final_row == 0 else guess_probs[v.final_row - 1]
+            mine = final_distribution(base.clone(), v.struck)
+            assert torch.allclose(mine, final["p"], atol=1e-6), trial
+        if v.accepted:
+            assert idx_ref == v.winner

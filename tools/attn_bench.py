@@ -40,7 +40,8 @@ def main():
                 n = ns if ns > 0 else ops.choose_splits(a.H, a.H // a.Hkv, T, P + T)
                 if os.environ.get("LADE_ATTN_DBG") == "16":
                     us, tl = ops.time_attn(q, k, vt, mask, H=a.H, Hkv=a.Hkv, d=a.d, n_splits=n, reps=a.reps, debug_timeline=True)
-                    nwg = a.Hkv * n * ((T * (a.H // a.Hkv) + 127) // 128)
+                    br = ops.attn_block_rows(a.H // a.Hkv, T) if not os.environ.get('LADE_ATTN_SHAPE') else int(os.environ['LADE_ATTN_SHAPE'])
+                    nwg = a.Hkv * n * ((T * (a.H // a.Hkv) + br - 1) // br)
                     tl = tl[:nwg].double()
                     rel = tl[:, 1:7] - tl[:, :1]
                     order = torch.argsort(tl[:, 0])
