@@ -1,25 +1,29 @@
 #!/usr/bin/env python
 """Benchmark of the lookahead-decoding hot path on MI355X.
 
-Metric (BASELINE.json): tokens/s + step-compression of greedy lookahead decoding on a synthetic
-random-weight Llama-2-7B-shaped model in bf16, W=15 N=5 G=15 (BASELINE config 2), 1/2/4/8 GPUs.
+Metric (BASELINE.json): tokens/s + step-compression of lookahead decoding on a synthetic random-weight Llama-shaped model,
+1/2/4/8 GPUs.  `--config` selects one of BASELINE.json's GPU configurations (the other configurations are parity-test cases):
 
-A "step" is one decode step of the lookahead loop = one model forward over T=(N-1)(W+g) tokens
-through the HIP hot path (input assembly, RoPE+KV append, lookahead attention, argmax, verify, pool
-insert, window roll, KV commit) with the weights, KV cache, window and n-gram pool resident in HBM.
-The prompt prefill and the N-2 window-fill steps are setup and are not timed; W warm-up steps and
-exactly K timed steps follow, bracketed by barrier + torch.cuda.synchronize().
+    c2 (default)  Llama-2-7B shape (32 L) bf16, greedy, W=15 N=5 G=15, prompt 2048               - the configuration the metric is quoted on
+    c3            same model, sampling (temperature 0.8), device-side verify
+    c4            CodeLlama-13B shape (40 L), greedy, W=20 N=7 G=20 (steps of 120..240 tokens)
+    c5            Llama-2-70B shape (80 L, GQA 64/8), greedy, lookahead-parallel code path (one rank with --gpus 1)
+
+A "step" is one decode step of the lookahead loop = one model forward over T=(N-1)(W+g) tokens through the HIP hot path (input
+assembly, RoPE+KV append, lookahead attention, argmax / probability table, verify, pool insert, window roll, KV commit) with the
+weights, KV cache, window and n-gram pool resident in HBM.  The prompt prefill and the N-2 window-fill steps are setup (the
+prefill is timed separately and reported as `prefill`); W warm-up + exactly K timed steps follow, bracketed by barrier +
+torch.cuda.synchronize(), MAX over ranks.
 
     python bench.py --gpus 1 --steps 32 --warmup 8
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+    python bench.py --gpus 8 ...            spawns its 8 ranks itself (one per GPU, RCCL), or is launched by torch.distributed.run
 
-With N > 1 the step runs lookahead-parallel (window columns + candidates sharded over the ranks, one
-RCCL all-gather of a small int32 record per step; lade/decoding.py:973-986, 1088-1107): total work
-per step is fixed, so scaling is "strong".
+With N > 1 the step runs lookahead-parallel (window columns + candidates sharded over the ranks, one RCCL all-gather of a small
+int32 record per step; lade/decoding.py:973-986, 1088-1107): total work per step is fixed, so scaling is "strong".
 
-Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (the attention kernel,
-algorithmic bytes / live hipEvent timing) and `cpu_baseline` (the CPU oracle = a port of the
-reference's greedy path, timed on this box's host cores on a bounded layer-sliced sample).
+Prints ONE JSON line (rank 0): the driver's contract plus `roofline` (the attention launch pair: algorithmic bytes / live hipEvent
+timing; MFMA fraction beside it), `prefill`, `plain_decode`, `hot_regime` and `cpu_baseline` (the CPU oracle = a port of the
+reference's path, timed on this box's host cores on a bounded sample).
 """
 from __future__ import annotations
 
@@ -27,6 +31,7 @@ import argparse
 import json
 import os
 import random
+import socket
 import sys
 import time
 
@@ -36,24 +41,33 @@ if ROOT not in sys.path:
 
 import torch
 
+CONFIGS = {
+    "c2": dict(model="llama2-7b", W=15, N=5, G=15, mode="greedy", what="BASELINE config 2: Llama-2-7B-chat shape, greedy"),
+    "c3": dict(model="llama2-7b", W=15, N=5, G=15, mode="sample", temperature=0.8, what="BASELINE config 3: Llama-2-7B-chat shape, sampling temperature 0.8"),
+    "c4": dict(model="codellama-13b", W=20, N=7, G=20, mode="greedy", what="BASELINE config 4: CodeLlama-13B shape, W=20 N=7 G=20 (long-guess verify branch)"),
+    "c5": dict(model="llama2-70b", W=15, N=5, G=15, mode="greedy", lp=True, what="BASELINE config 5: Llama-2-70B shape (GQA 64/8), lookahead-parallel path"),
+}
 
-def parse():
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--model", default="llama2-7b")
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--model", default=None, help="override the config's model shape")
     ap.add_argument("--layers", type=int, default=0, help="override the layer count (debug only; invalidates the metric)")
-    ap.add_argument("--window", type=int, default=15)
-    ap.add_argument("--level", type=int, default=5)
-    ap.add_argument("--guess", type=int, default=15)
+    ap.add_argument("--window", type=int, default=0)
+    ap.add_argument("--level", type=int, default=0)
+    ap.add_argument("--guess", type=int, default=-1)
     ap.add_argument("--prompt-len", type=int, default=2048)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--no-graph", action="store_true", help="run steady steps eagerly instead of replaying the captured hipGraph")
-    ap.add_argument("--force-lp", action="store_true", help="run the lookahead-parallel code path even with one rank (debug)")
+    ap.add_argument("--force-lp", action="store_true", help="run the lookahead-parallel code path even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip plain_decode / hot_regime / graph_delta (profiling runs)")
     ap.add_argument("--cpu-baseline-steps", type=int, default=3)
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def attn_algorithmic_bytes(cfg, T, P, elem=2):
@@ -62,19 +76,27 @@ def attn_algorithmic_bytes(cfg, T, P, elem=2):
     return elem * (2 * Hkv * (P + T) * d + 2 * H * T * d)
 
 
+def attn_useful_flops(cfg, T, P, W, N, g):
+    """K1 useful flops = 4*d*H*(T*P + vis), vis = visible (query, new key) pairs of the closed-form mask"""
+    gs = N - 1
+    vis = (N - 1) * W * (W + 1) // 2 + W * (N - 1) * (N - 2) // 2 + g * gs * (gs + 3) // 2
+    return 4 * cfg["head_dim"] * cfg["heads"] * (T * P + vis)
+
+
 def pmc_traffic(T, P, n_splits):
-    """HBM bytes per launch pair from the rocprofv3 PMC passes committed under profiles/ (bench.py cannot collect
-    counters itself): FETCH_SIZE (x2 on gfx950 for wide coalesced reads, MI355X_MICROARCH.md HBM section) + WRITE_SIZE,
-    KiB -> bytes, attention + combine kernels.  Only reported when the profiled shape matches this run's shape."""
-    path = os.path.join(ROOT, "profiles", "r1_attn_pmc.json")
-    try:
-        with open(path) as f:
-            for e in json.load(f)["entries"]:
-                if e["T"] == T and abs(e["P"] - P) <= 64 and e["n_splits"] == n_splits:
-                    return e["traffic_bytes"]
-    except Exception:
-        pass
-    return None
+    """HBM bytes per launch pair from the rocprofv3 PMC passes committed under profiles/ (bench.py cannot collect counters
+    itself): FETCH_SIZE (x2 on gfx950 for wide coalesced reads, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KiB -> bytes,
+    attention + combine kernels.  Only reported when a profiled shape matches this run's shape; returns (bytes, source file)."""
+    for name in ("r2_attn_pmc.json", "r1_attn_pmc.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            with open(path) as f:
+                for e in json.load(f)["entries"]:
+                    if e["T"] == T and abs(e["P"] - P) <= 64 and e["n_splits"] == n_splits:
+                        return e["traffic_bytes"], f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/attn_bench.py at this shape; not collected by this run)"
+        except Exception:
+            pass
+    return None, None
 
 
 def host_cores() -> int:
@@ -89,17 +111,70 @@ def host_cores() -> int:
     return n
 
 
-def cpu_baseline(args, cfg_full):
-    """The reference's CPU greedy path cannot travel to this box; its port (oracle/lade_oracle.py, pinned
-    to reference-generated traces) is timed instead, fp32, all host cores, on a bounded sample: a
-    layer-sliced model of the same widths, short prompt, a few steady steps; the per-layer time is
-    extrapolated to the full depth."""
+def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import lade_oracle as O
+    return O
+
+
+def cpu_baseline_full_depth(c, cfg_full, prompt_len, n_steps):
+    """the reference's CPU greedy path at FULL depth on this box's cores.  The reference itself cannot
+    travel here; its port (oracle/lade_oracle.py, pinned to reference-generated traces) is timed: fp32 weights of the full model
+    (27 GB for the 7B shape), a KV cache of the bench's own prompt length filled with synthetic rows (the timing of a steady step
+    does not depend on the cached values; prefilling 2048 tokens on the CPU would take minutes), then `n_steps` steady lookahead
+    steps (model_step = jforward_multilevel: dense fp32 mask, torch.cat of the cache, lm_head rows, as the reference does).
+    Returns None when the host does not have the memory."""
+    O = _oracle()
+    from lookaheaddecoding_amd.weights import weight_shapes
+    n_param = sum(int(torch.tensor(s).prod()) for s in weight_shapes(cfg_full).values())
+    need = n_param * 4 * 1.15 + 4e9
+    try:
+        import psutil
+        if psutil.virtual_memory().available < need:
+            return None
+    except Exception:
+        return None
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    W, N, G = c["W"], c["N"], c["G"]
+    gs = N - 1
+    g = torch.Generator().manual_seed(0)
+    w = {}
+    t_build = time.time()
+    for k, shp in weight_shapes(cfg_full).items():
+        w[k] = torch.ones(shp) if len(shp) == 1 else torch.empty(shp).normal_(0, 0.02, generator=g)
+    model = O.OracleLlama(dict(cfg_full, max_pos=prompt_len + 512), w)
+    cache = [[torch.randn(model.Hkv, prompt_len, model.d, generator=g), torch.randn(model.Hkv, prompt_len, model.d, generator=g)] for _ in range(model.L)]
+    t_build = time.time() - t_build
+    rnd = lambda n: torch.randint(3, cfg_full["vocab"], (n,), generator=g).tolist()
+    past = [rnd(W - 1)] + [rnd(W) for _ in range(N - 2)]
+    times, T = [], 0
+    for i in range(1 + n_steps):
+        t0 = time.time()
+        out = O.model_step(model, cache, [5], [prompt_len], past, None, N - 2, gs)       # cold regime: no candidates, one token accepted
+        torch.argmax(out.inp_logits, dim=-1)
+        dt = time.time() - t0
+        T = out.layout.T
+        O.kv_truncate(cache, prompt_len)
+        if i > 0:                                  # the first call pays page faults / thread pool start-up
+            times.append(dt)
+    step_s = sum(times) / len(times)
+    del model, w, cache
+    return {"value": round(1.0 / step_s, 4), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/lade_oracle.py (port of lade/decoding.py:697-1259 + modeling_llama.py eager path), fp32, {cores} threads, FULL depth "
+                      f"({cfg_full['layers']} layers, {n_param * 4 / 1e9:.1f} GB of weights built in {t_build:.0f} s), KV cache of {prompt_len} synthetic rows, "
+                      f"{n_steps} steady steps of T={T} tokens after one untimed step, W={W} N={N} G={G}, S=1.0 (cold regime: 1 token/step)",
+            "s_per_step": round(step_s, 4)}
+
+
+def cpu_baseline_sliced(c, cfg_full, model_name, n_steps):
+    """Layer-sliced sample for the shapes whose full depth does not fit the time budget (13B / 70B): 1- and 2-layer models of the
+    same widths, short prompt, a few steady steps of the oracle loop; the per-layer time is extrapolated to the full depth."""
+    O = _oracle()
     from lookaheaddecoding_amd.weights import make_config, weight_shapes
     cores = host_cores()
     torch.set_num_threads(cores)
-    W, N, G = args.window, args.level, args.guess
+    W, N, G = c["W"], c["N"], c["G"]
     prompt_len = 64
     times = {}
     for Ls in (1, 2):
@@ -110,8 +185,7 @@ def cpu_baseline(args, cfg_full):
             w[k] = torch.ones(shp) if len(shp) == 1 else torch.empty(shp).normal_(0, 0.02, generator=g)
         model = O.OracleLlama(cfg, w)
         prompt = torch.randint(3, cfg["vocab"], (prompt_len,), generator=torch.Generator().manual_seed(123)).tolist()
-        n_steps = (N - 1) + args.cpu_baseline_steps
-        # time whole steps of the oracle loop; the last `cpu_baseline_steps` are steady steps
+        total = (N - 1) + n_steps
         t_marks = []
         orig = O.model_step
 
@@ -123,34 +197,47 @@ def cpu_baseline(args, cfg_full):
 
         O.model_step = timed_step
         try:
-            res = O.lookahead_greedy(model, prompt, W, N, G, prompt_len + n_steps, random.Random(1), keep_trace=False)
+            O.lookahead_greedy(model, prompt, W, N, G, prompt_len + total, random.Random(1), keep_trace=False)
         finally:
             O.model_step = orig
         steady = t_marks[N - 1:]
-        times[Ls] = (sum(t for t, _ in steady) / max(1, len(steady)), sum(T for _, T in steady) / max(1, len(steady)), res.steps)
+        times[Ls] = (sum(t for t, _ in steady) / max(1, len(steady)), sum(T for _, T in steady) / max(1, len(steady)))
         del model, w
     per_layer = max(times[2][0] - times[1][0], 1e-9)
     fixed = max(times[1][0] - per_layer, 0.0)
     step_s = fixed + cfg_full["layers"] * per_layer
     return {"value": round(1.0 / step_s, 4), "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/lade_oracle.py (port of lade/decoding.py:697-1259 + modeling_llama.py eager path), fp32, {cores} threads; "
-                      f"layer-sliced {args.model} shape (1 and 2 layers -> per-layer {per_layer * 1e3:.1f} ms, fixed {fixed * 1e3:.1f} ms, "
-                      f"extrapolated to {cfg_full['layers']} layers = {step_s:.2f} s/step), prompt {prompt_len}, {args.cpu_baseline_steps} steady steps, "
-                      f"W={W} N={N} G={G}, T~{times[2][1]:.0f} tokens/step, S=1.0 (cold regime: 1 token/step)",
+            "sample": f"oracle/lade_oracle.py (port of lade/decoding.py:697-1259 + modeling_llama.py eager path), fp32, {cores} threads; layer-sliced "
+                      f"{model_name} shape (1 and 2 layers -> per-layer {per_layer * 1e3:.1f} ms, fixed {fixed * 1e3:.1f} ms, scaled x{cfg_full['layers']} layers = "
+                      f"{step_s:.2f} s/step; full depth not run: {cfg_full['layers']} layers of this width exceed the bench's CPU time budget), prompt {prompt_len}, "
+                      f"{n_steps} steady steps, W={W} N={N} G={G}, T~{times[2][1]:.0f} tokens/step, S=1.0 (cold regime: 1 token/step)",
             "s_per_step": round(step_s, 4)}
 
 
-def main():
-    args = parse()
+def worker(args):
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    if args.gpus != world and world > 1:
+    c = dict(CONFIGS[args.config])
+    if args.model:
+        c["model"] = args.model
+    if args.window:
+        c["W"] = args.window
+    if args.level:
+        c["N"] = args.level
+    if args.guess >= 0:
+        c["G"] = args.guess
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank} needs cuda:{local_rank}, this box has {torch.cuda.device_count()} GPU(s)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    use_lp = world > 1 or args.force_lp
+    use_lp = world > 1 or args.force_lp or bool(c.get("lp"))
+    sampling = c["mode"] == "sample"
+    if sampling and use_lp:
+        raise SystemExit("the sampling path has no lookahead parallelism (neither has the reference)")
     if use_lp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -160,19 +247,20 @@ def main():
     from lookaheaddecoding_amd import ops
     from lookaheaddecoding_amd.decoding import LookaheadDecoder
     from lookaheaddecoding_amd.engine import StepEngine
+    from lookaheaddecoding_amd.sampling import make_warper
     from lookaheaddecoding_amd.weights import make_config, random_weights_torch
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
-    cfg = make_config(args.model)
+    cfg = make_config(c["model"])
     if args.layers:
         cfg["layers"] = args.layers
-    W, N, G = args.window, args.level, args.guess
+    W, N, G = c["W"], c["N"], c["G"]
     gs = N - 1
-    total_steps = (N - 1) + args.warmup + args.steps + 2
+    total_steps = (N - 1) + args.warmup + args.steps + 8
     max_seq = args.prompt_len + total_steps * N + (N - 1) * (W + G) + 64
     cfg["max_pos"] = max(cfg.get("max_pos", 4096), max_seq)
     weights = random_weights_torch(cfg, seed=0, dtype=dtype, device=dev)
-    eng = StepEngine(cfg, weights, dtype=dtype, device=dev, max_seq=max_seq, max_T=512)
+    eng = StepEngine(cfg, weights, dtype=dtype, device=dev, max_seq=max_seq, max_T=512, consume_weights=True)
     del weights
     lp = None
     if use_lp:
@@ -186,12 +274,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    class SampleRun:                                 # the stepwise sampling API behind the same start / step interface
+        def __init__(self, d):
+            self.d = d
+
+        def start(self, p, rng=None):
+            self.d.sample_start(p, warp=make_warper(temperature=c.get("temperature", 1.0)), rng=rng, torch_gen=torch.Generator(device=dev).manual_seed(1))     # draws stay on the GPU
+
+        def step(self):
+            return self.d.sample_step()
+
+        tokens = property(lambda self: self.d.tokens)
+        P = property(lambda self: self.d.P)
+
     run = dec
     if use_lp:
         from lookaheaddecoding_amd.parallel import LPRunner
         run = LPRunner(dec)
+    elif sampling:
+        run = SampleRun(dec)
     run.start(prompt, rng=random.Random(1))
-    for _ in range(N - 1):                       # prefill + window fill: setup, untimed
+    run.step()                                   # untimed: first-call costs (GEMM autotune of the last chunk's row class, library handles)
+    run.start(prompt, rng=random.Random(1))
+    sync()
+    tp0 = time.perf_counter()
+    run.step()                                   # prefill of the prompt + first window level (causal chunks of <= 512 rows)
+    sync()
+    prefill_s = time.perf_counter() - tp0
+    for _ in range(N - 2):                       # window fill: setup, untimed
         run.step()
     for _ in range(args.warmup):
         run.step()
@@ -204,20 +314,21 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if use_lp:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed, prefill_s], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed, prefill_s = float(tmax[0].item()), float(tmax[1].item())
     new_tokens = len(run.tokens) - tok0
     S = new_tokens / args.steps
     Ts = [i["T"] for i in infos if i.get("T")]
     avg_T = (sum(Ts) / len(Ts)) if Ts else float((N - 1) * W)
     P_end = run.P
+    extras = rank == 0 and not use_lp and not sampling and not args.no_extras
 
-    # ---- the attention launch pair timed IN the step: a few more steady steps, eager, with a hipEvent before the
-    # attention launch and after the split merge of every layer (torch's current stream is the launch stream) ----
+    # ---- the attention launch pair timed IN the step: a few more steady steps, eager, with a hipEvent before the attention launch
+    # and after the split merge of every layer (torch's current stream is the launch stream) ----
     in_situ = None
-    if rank == 0 and not use_lp:
-        was_graph, run.use_graph = run.use_graph, False
+    if rank == 0 and not use_lp and not args.no_extras:
+        was_graph, dec.use_graph = dec.use_graph, False
         run.step()                                   # first eager step: one-off costs (autotune of a new row class ...)
         sync()
         eng.attn_events = []
@@ -226,21 +337,21 @@ def main():
             run.step()
         sync()
         eager_ms = (time.perf_counter() - te0) / 4 * 1e3
-        evs, eng.attn_events, run.use_graph = eng.attn_events, None, was_graph
+        evs, eng.attn_events, dec.use_graph = eng.attn_events, None, was_graph
         T_ref = int(round(avg_T))
         evs = [e for e in evs if e[2] == T_ref] or evs           # launches of the steady shape only (a stray candidate changes T)
         durs = sorted(e0.elapsed_time(e1) * 1e3 for (e0, e1, _, _) in evs)
         if durs:
-            # eager launches keep the GPU busy only when a step's GPU time exceeds its host launch time; otherwise the
-            # bracket also contains host gaps (small models) and the isolated timing is reported instead
+            # eager launches keep the GPU busy only when a step's GPU time exceeds its host launch time; otherwise the bracket also
+            # contains host gaps (small models) and the graph difference / isolated timing is reported instead
             gpu_bound = eager_ms <= 1.15 * (elapsed / args.steps * 1e3)
             in_situ = {"us": sum(durs) / len(durs), "median_us": durs[len(durs) // 2], "T": evs[-1][2], "n_splits": evs[-1][3], "P": run.P,
                        "launches": len(durs), "eager_ms_per_step": round(eager_ms, 3), "gpu_bound": bool(gpu_bound)}
 
-    # ---- the same pair as a step-time difference: a second decoder over the same engine with the attention launches left
-    # out, same hipGraph mode, same shapes (random weights: no candidates either way) - independent of the host's launch rate
+    # ---- the same pair as a step-time difference: a second decoder over the same engine with the attention launches left out,
+    # same hipGraph mode, same shapes (random weights: no candidates either way) - independent of the host's launch rate
     graph_delta = None
-    if rank == 0 and not use_lp and not args.no_graph:
+    if extras and not args.no_graph:
         eng.skip_attn = True
         d2 = LookaheadDecoder(eng, W, N, 0, use_graph=True)      # no candidates: the garbage logits must not change the step shape
         d2.start(prompt, rng=random.Random(1))
@@ -257,10 +368,10 @@ def main():
         if abs(T2 - avg_T) <= 4 and all(same_class(i["T"]) == same_class(int(round(avg_T))) for i in i2):      # same GEMM row class throughout
             graph_delta = {"us": (elapsed / args.steps * 1e3 - ms_noattn) / cfg["layers"] * 1e3, "ms_per_step_without_attention": round(ms_noattn, 3)}
 
-    # ---- plain autoregressive decoding on the same engine and cache length (one token per forward, T = 1): what
-    # lookahead decoding has to beat; S * (plain step / lookahead step) is its speed-up
+    # ---- plain autoregressive decoding on the same engine and cache length (one token per forward, T = 1): what lookahead
+    # decoding has to beat; S * (plain step / lookahead step) is its speed-up
     plain = None
-    if rank == 0 and not use_lp:
+    if extras:
         one_id = torch.full((1,), 5, dtype=torch.int32, device=dev)
         one_pos = torch.full((1,), P_end, dtype=torch.int32, device=dev)
         sel0 = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -275,31 +386,29 @@ def main():
         with torch.cuda.graph(gph):
             plain_step()
         sync()
-        tp0 = time.perf_counter()
+        tpl = time.perf_counter()
         for _ in range(args.steps):
             gph.replay()
         sync()
-        ms_plain = (time.perf_counter() - tp0) / args.steps * 1e3
+        ms_plain = (time.perf_counter() - tpl) / args.steps * 1e3
         plain = {"value": round(1e3 / ms_plain, 2), "unit": "tokens/s", "ms_per_token": round(ms_plain, 3),
                  "how": f"one-token forward + argmax as a hipGraph at cache length {P_end}, same engine and kernels"}
 
-    # ---- hot regime, measured last because it overwrites weights.  Random weights never accept a
-    # candidate (S = 1).  To time the accept path under load the model is turned into a deterministic successor map:
-    # every layer's o_proj / down_proj zeroed (the residual stream keeps the input embedding) and lm_head row j set to
-    # embed[(j-1) mod C] for j < C, so the greedy continuation of token t is (t+1) mod C; the prompt walks that cycle
-    # and POOL_FROM_PROMPT seeds the pool, so every step verifies a full n-gram (S -> N-1).  Same kernels, same bytes.
+    # ---- hot regime, measured last because it overwrites weights.  Random weights never accept a candidate (S = 1).
+    # To time the accept path under load the model is turned into a deterministic successor map: every layer's o_proj / down_proj
+    # zeroed (the residual stream keeps the input embedding) and lm_head row j set to embed[(j-1) mod C] for j < C, so the greedy
+    # continuation of token t is (t+1) mod C; the prompt walks that cycle and POOL_FROM_PROMPT seeds the pool, so every step
+    # verifies a full n-gram (S -> N-1).  Same kernels, same bytes.
     def hot_regime():
-        if use_lp:
-            return None
-        C = 256
+        Cy = 256
         for lw in eng.layers:
             lw["wo"].zero_()
             lw["wd"].zero_()
         head = eng.embed.clone()
-        head[:C] = eng.embed[(torch.arange(C, device=dev) - 1) % C]
+        head[:Cy] = eng.embed[(torch.arange(Cy, device=dev) - 1) % Cy]
         eng.lm_head = head
         hot_dec = LookaheadDecoder(eng, W, N, G, pool_from_prompt=True, use_graph=not args.no_graph)
-        hot_prompt = [i % C for i in range(args.prompt_len)]
+        hot_prompt = [i % Cy for i in range(args.prompt_len)]
         hot_dec.start(hot_prompt, rng=random.Random(1))
         for _ in range(N - 1 + args.warmup):
             hot_dec.step()
@@ -310,62 +419,110 @@ def main():
         sync()
         th = time.perf_counter() - th0
         gen = hot_dec.tokens[tok_h:]
-        ok = all(gen[i + 1] == (gen[i] + 1) % C for i in range(len(gen) - 1))
+        ok = all(gen[i + 1] == (gen[i] + 1) % Cy for i in range(len(gen) - 1))
         return {"value": round(len(gen) / th, 2), "unit": "tokens/s", "step_compression": round(len(gen) / args.steps, 3),
                 "ms_per_step": round(th / args.steps * 1e3, 3), "tokens_per_step_T": round(sum(i["T"] for i in hot_infos) / len(hot_infos), 1),
                 "output_is_the_successor_cycle": ok,
                 "how": "successor-map model (o_proj/down_proj zeroed, lm_head = shifted embedding), cyclic prompt, POOL_FROM_PROMPT=1"}
 
-    out = None
     if rank == 0:
         # ---- roofline of the dominant hand-written kernel: lookahead attention, one layer ----
         T_mid = int(round(avg_T))
-        g_mid = max(0, (T_mid - (N - 1) * W) // gs)
-        T_k = (N - 1) * W + g_mid * gs
-        mask = ops.StepMask.from_levels(1, [W - 1] + [W] * (N - 2), g_mid * gs, gs, P_end)
+        if use_lp:                                   # a rank's own shard: re-derive it from the runner's partition
+            from lookaheaddecoding_amd.parallel import shard_level_sizes, window_shard
+            c0, c1 = window_shard(W, world, rank)
+            ls = shard_level_sizes([W - 1] + [W] * (N - 2), c0, c1)
+            g_mid = 0
+            mask = ops.StepMask.from_levels(1, ls, 0, gs, P_end)
+        else:
+            g_mid = max(0, (T_mid - (N - 1) * W) // gs)
+            mask = ops.StepMask.from_levels(1, [W - 1] + [W] * (N - 2), g_mid * gs, gs, P_end)
+        T_k = mask.T
         qkv = torch.randn(T_k, (cfg["heads"] + 2 * cfg["kv_heads"]) * cfg["head_dim"], device=dev).to(dtype)
         ns = eng.n_splits_for(T_k, P_end + T_k)
-        # every repetition uses the next layer's K/V cache (L caches of 2*Hkv*S_max*d*e bytes >> the 256 MB Infinity Cache), so
-        # the launch streams its keys/values from HBM exactly as inside a decode step
+        # every repetition uses the next layer's K/V cache (L caches of 2*Hkv*S_max*d*e bytes >> the 256 MB Infinity Cache), so the
+        # launch streams its keys/values from HBM exactly as inside a decode step
         us = ops.time_attn(qkv, [eng.k_cache(li) for li in range(eng.L)], [eng.vt_cache(li) for li in range(eng.L)], mask,
                            H=cfg["heads"], Hkv=cfg["kv_heads"], d=cfg["head_dim"], n_splits=ns, reps=max(200, 8 * eng.L))
-        us_iso = us
+        us_iso, how = us, "isolated (no in-step measurement in this mode)"
         if in_situ is not None and in_situ["T"] == T_k and in_situ["gpu_bound"]:
-            us, ns = in_situ["us"], in_situ["n_splits"]
+            us, ns, how = in_situ["us"], in_situ["n_splits"], "hipEvents inside real decode steps"
         elif graph_delta is not None and graph_delta["us"] > 0:
-            us = graph_delta["us"]
+            us, how = graph_delta["us"], "hipGraph step time with / without the attention launches"
         alg = attn_algorithmic_bytes(cfg, T_k, P_end)
+        flops = attn_useful_flops(cfg, T_k, P_end, W, N, g_mid) if not use_lp else 4 * cfg["head_dim"] * cfg["heads"] * T_k * P_end
         achieved = alg / (us * 1e-6) / 1e9
+        traffic, traffic_source = pmc_traffic(T_k, P_end, ns)
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
-                    "traffic": pmc_traffic(T_k, P_end, ns), "kernel": f"lade::attn_fwd_kernel<{args.dtype},{cfg['head_dim']}> (+combine, n_splits={ns})",
-                    "launch_us": round(us, 2), "algorithmic_bytes": alg, "T": T_k, "P": P_end,
+                    "traffic": traffic, "traffic_source": traffic_source,
+                    "kernel": f"lade::attn_fwd_kernel<{args.dtype},{cfg['head_dim']}> (+combine, n_splits={ns})",
+                    "launch_us": round(us, 2), "launch_us_source": how, "algorithmic_bytes": alg, "T": T_k, "P": P_end,
+                    "mfma": {"useful_flops": flops, "achieved_tflops": round(flops / (us * 1e-6) / 1e12, 1), "peak_tflops": 2500.0,
+                             "frac": round(flops / (us * 1e-6) / 1e12 / 2500.0, 4),
+                             "note": "useful flops of the closed-form mask (SURVEY 8d) / the same launch time / dense bf16 MFMA peak; utilisation counters: profiles/r2_attn_mfma_*.csv"},
                     "launch_us_in_step": None if in_situ is None else {k: (round(v, 2) if isinstance(v, float) else v) for k, v in in_situ.items()},
                     "launch_us_graph_delta": None if graph_delta is None else {k: (round(v, 2) if isinstance(v, float) else v) for k, v in graph_delta.items()},
                     "launch_us_isolated": round(us_iso, 2),
-                    "note": "launch_us = one layer's launch pair (attention + split merge) bracketed by hipEvents on the launch stream INSIDE real decode steps "
-                            "(4 eager steady steps after the timed region, every layer), mean - used when those eager steps are GPU bound "
-                            "(launch_us_in_step.gpu_bound), else launch_us_graph_delta = (graph step time - graph step time with the attention launches "
-                            "left out) / layers; launch_us_isolated = the same pair launched back to back "
-                            "(lade_time_attn_rot, cycling through the layers' K/V caches so that every launch reads HBM)"}
-        hot = hot_regime()
+                    "note": "launch_us = one layer's launch pair (attention + split merge): bracketed by hipEvents on the launch stream INSIDE real decode "
+                            "steps (4 eager steady steps after the timed region, every layer; used when those steps are GPU bound), else (graph step "
+                            "time - graph step time without the attention launches) / layers, else isolated back-to-back launches cycling through the "
+                            "layers' K/V caches (every launch reads HBM)"}
+        hot = hot_regime() if extras else None
         cpu = None
         if not args.no_cpu_baseline and world == 1:            # the CPU baseline is timed at N=1 only
-            cpu = cpu_baseline(args, cfg)
+            if args.config in ("c2", "c3") and not args.layers:
+                cpu = cpu_baseline_full_depth(c, cfg, args.prompt_len, args.cpu_baseline_steps)
+            if cpu is None:
+                cpu = cpu_baseline_sliced(c, cfg, c["model"], args.cpu_baseline_steps)
+        mode = "sampling (temperature %.2f)" % c["temperature"] if sampling else "greedy"
         out = {
-            "metric": "tokens/s, greedy lookahead decoding (W=15,N=5,G=15)" if (W, N, G) == (15, 5, 15) else f"tokens/s, greedy lookahead decoding (W={W},N={N},G={G})",
+            "metric": f"tokens/s, {mode} lookahead decoding (W={W},N={N},G={G})",
             "value": round(new_tokens / elapsed, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (random-init weights, random prompt ids)",
-            "config": {"workload": f"{args.model}-shape ({cfg['layers']}L) {args.dtype} greedy lookahead, 1 sequence, prompt {args.prompt_len}, "
-                                   f"W={W} N={N} G={G}, cold regime (untied random weights)", "parallelism": f"lp{world}" if use_lp else "single",
-                       "tokens_per_step_T": round(avg_T, 1), "kv_len_end": P_end, "hipgraph": bool(dec.use_graph)},
+            "config": {"workload": f"{c['what']}; {c['model']}-shape ({cfg['layers']}L) {args.dtype} {mode} lookahead, 1 sequence, prompt {args.prompt_len}, "
+                                   f"W={W} N={N} G={G}, cold regime (untied random weights)", "name": args.config,
+                       "parallelism": f"lp{world}" if use_lp else "single", "tokens_per_step_T": round(avg_T, 1), "kv_len_end": P_end,
+                       "hipgraph": bool(dec.use_graph)},
             "step_compression": round(S, 3), "steps_per_s": round(args.steps / elapsed, 2),
+            "prefill": {"tokens": args.prompt_len + W + N - 3, "ms": round(prefill_s * 1e3, 2), "tokens_per_s": round((args.prompt_len + W + N - 3) / prefill_s, 1),
+                        "how": "prompt + first window level as causal chunks of <= 512 rows through the same attention / GEMM kernels, lm_head on the "
+                               "rows that are read only; second prefill of the process (the first one pays the one-off GEMM autotune)"},
             "hot_regime": hot, "plain_decode": plain, "roofline": roofline, "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
     if use_lp:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: anything the native libraries still hold in C stdio buffers (the RCCL version
+        # banner) is flushed first
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
+
+
+def _spawned(local_rank, n, port, argv):
+    os.environ.update(RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    worker(parse(argv))
+
+
+def main():
+    args = parse()
+    if "WORLD_SIZE" in os.environ or args.gpus <= 1:       # launched by torch.distributed.run (one rank per process), or a single GPU
+        os.environ.setdefault("WORLD_SIZE", "1")
+        return worker(args)
+    # `python bench.py --gpus N`: start the N ranks ourselves, one process per GPU, RCCL over xGMI between them
+    if torch.cuda.device_count() < args.gpus:
+        raise SystemExit(f"--gpus {args.gpus}: this box has {torch.cuda.device_count()} GPU(s)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    import torch.multiprocessing as mp
+    mp.spawn(_spawned, args=(args.gpus, port, sys.argv[1:]), nprocs=args.gpus, join=True)
 
 
 if __name__ == "__main__":

@@ -316,18 +316,31 @@ class LookaheadDecoder:
                              am_host=torch.zeros(self.W, dtype=torch.int32).pin_memory())
         return self._smp
 
-    def _draw(self, src: torch.Tensor, row: int, temperature: float, struck: Sequence[int], torch_gen: Optional[torch.Generator]) -> int:
+    def _draw(self, src: torch.Tensor, row: int, temperature: float, struck: Sequence[int], torch_gen: Optional[torch.Generator]):
         """One token from the distribution of logits row `row` (softmax on the device) with the struck drafts removed.  A CUDA
-        generator keeps the draw on the device (what the reference does with the model on a GPU); otherwise the one row goes to
-        the host and torch.multinomial consumes the CPU generator (reproducible against the CPU-generated reference traces)."""
+        generator keeps the draw on the device (what the reference does with the model on a GPU): the token is returned as a
+        device tensor and reaches the host with the step's record.  Otherwise the one row goes to the host and
+        torch.multinomial consumes the CPU generator (reproducible against the CPU-generated reference traces): returns an int."""
         from .sampling import final_distribution
         b = self._sampling_buffers()
         probs = ops.softmax_rows(src[row:row + 1], temperature, out=b["probs"])[0]
         if torch_gen is not None and torch_gen.device.type == "cuda":
-            return int(torch.multinomial(final_distribution(probs, struck), num_samples=1, generator=torch_gen).item())
+            return torch.multinomial(final_distribution(probs, struck), num_samples=1, generator=torch_gen).to(torch.int32)
         b["probs_host"].copy_(probs, non_blocking=True)
         torch.cuda.current_stream().synchronize()
         return int(torch.multinomial(final_distribution(b["probs_host"].clone(), struck), num_samples=1, generator=torch_gen).item())
+
+    @torch.no_grad()
+    @_on_device
+    def sample_start(self, prompt: Sequence[int], warp=None, eos_token_id: Optional[int] = None, rng: Optional[random.Random] = None,
+                     torch_gen: Optional[torch.Generator] = None) -> None:
+        """Begins a sampling run (`sample` = sample_start + sample_step until done; bench.py drives single steps)."""
+        e, W = self.e, self.W
+        rng = rng if rng is not None else random
+        self.start(prompt, eos_token_id, rng)
+        self._s = dict(warp=warp, fused_T=1.0 if warp is None else getattr(warp, "fused_temperature", None), rng=rng, torch_gen=torch_gen,
+                       old=list(self.prompt), forced=torch.zeros(2 + cabi.MAX_LEVEL, dtype=torch.int32, device=e.device),
+                       override=torch.zeros(W, dtype=torch.int32, device=e.device))
 
     @torch.no_grad()
     @_on_device
@@ -342,110 +355,122 @@ class LookaheadDecoder:
         one `torch.multinomial` for the token that ends the step (:484-540), and the `filter_window` draws (:578-580).
         `warp`: a sampling.Warper (temperature / top-k / top-p; temperature alone is applied inside the kernels) or any callable
         mapping fp32 logits rows [r, V] to warped logits (the HF warpers the reference admits, :375-377)."""
-        from .sampling import resolve_drafts
-        e, st = self.e, self.st
-        W, N, G, gs = self.W, self.N, self.G, self.gs
-        rng = rng if rng is not None else random
-        fused_T = 1.0 if warp is None else getattr(warp, "fused_temperature", None)
-        self.start(prompt, eos_token_id, rng)
-        all_old_tokens = list(self.prompt)
-        buf = self._sampling_buffers()
-        forced = torch.zeros(2 + cabi.MAX_LEVEL, dtype=torch.int32, device=e.device)
-        override = torch.zeros(W, dtype=torch.int32, device=e.device)
+        self.sample_start(prompt, warp, eos_token_id, rng, torch_gen)
         trace: List[dict] = []
         while True:
-            prompt_l, P, g, fill_level = self.prompt, self.P, self.g, self.fill_level
-            P_before = P
-            if self.steps == 0:
-                phase = 0
-                ids_h = prompt_l + self.window0
-                n_inp, cand_rows = len(self.window0), 0
-                logits, done = e.prefill(ids_h, [len(prompt_l) - 1] + list(range(len(prompt_l), len(ids_h))))
-                logits = logits.float()
-                ops.argmax_rows(logits, out=st.am)
-                T, P_before = len(ids_h) - done, done
-            elif self.use_graph and fill_level >= N - 2:
-                # steady step: input assembly + model step + argmax replayed as one hipGraph (candidate rows padded to the bucket)
-                if self._graph != "forward" or self._graph_gen != e.generation:
-                    self._capture_graphs(forward_only=True)
-                phase, n_inp = 2, W
-                gcap = self._bucket_for(g)
-                T, cand_rows = self._graph_T[gcap], gcap * gs
-                if abs(e.n_splits_for(T, P + T) - self._graph_splits[gcap]) >= 2:
-                    self._capture_graphs(forward_only=True)
-                if P + T > e.S_max:
-                    raise cabi.LadeHipError(f"KV cache exhausted: P={P} + T={T} > S_max={e.S_max}")
-                self._graphs[gcap].replay()
-                logits = self._graph_logits[gcap]
-            else:
-                phase = 2 if fill_level >= N - 2 else 1
-                ls = self._level_sizes(fill_level)
-                cand_rows = g * gs if phase == 2 else 0
-                mask = StepMask.from_levels(1, ls, cand_rows, gs, P)
-                T = mask.T
-                call("lade_build_inputs", None, None, 1, ptr(st.window), st.wcap, ptr(st.ctl), min(fill_level, N - 2), 0, -1,
-                     ptr(st.guess), g if phase == 2 else 0, gs, cand_rows, ptr(st.ids), ptr(st.pos), None)
-                n_inp = ls[-1]
-                n_sel = self._set_sel([0] + list(range(T - cand_rows - n_inp, T - cand_rows)) + list(range(T - cand_rows, T)))
-                logits = e.forward(st.ids, st.pos, mask, st.sel, n_sel).float()    # logits.float(), modeling_llama.py:1544
-                ops.argmax_rows(logits, out=st.am)                                    # window levels are filled by argmax (:459, :545)
-            step_inputs = {}
-            if keep_trace and phase != 0:                            # what the step fed and judged (tests re-derive the probabilities)
-                step_inputs = dict(ids=st.ids[:T].tolist(), pos=st.pos[:T].tolist(), level_sizes=list(self._level_sizes(fill_level)),
-                                   cand_rows=cand_rows, g=g, drafts=st.guess[:g * gs].tolist() if phase == 2 else [])
-            # ---- the step's token(s): rejection-sampling verify over the candidates, or a plain draw (:453-540) ----
-            verify = phase == 2 and g > 0
-            rows = 1 + g * gs if verify else 1
-            if fused_T is not None:                              # temperature only: the kernels scale the logits themselves
-                src, skip, temp = logits, n_inp, fused_T
-            else:                                                # top-k / top-p / HF warper objects: warped on the device by torch
-                picked = logits[0:1] if not verify else torch.cat([logits[0:1], logits[1 + n_inp:1 + n_inp + g * gs]])
-                src, skip, temp = warp(picked), 0, 1.0
-            max_hit_idx = 0
-            if verify:
-                ops.softmax_gather(src, rows, skip, st.guess, g, gs, max(G, 1), temp, buf["scal"], buf["stats"])
-                buf["scal_host"].copy_(buf["scal"], non_blocking=True)
-                buf["guess_host"].copy_(st.guess, non_blocking=True)
-                torch.cuda.current_stream().synchronize()                      # the step's one table read-back
-                table = buf["scal_host"].view(-1, max(G, 1))[:rows].tolist()
-                if keep_trace:
-                    step_inputs["table"] = table
-                verdict = resolve_drafts(table, buf["guess_host"][:g * gs].tolist(), g, gs, rng.random)
-                hits, max_hit_idx = list(verdict.accepted), verdict.winner
-                if verdict.final_row is not None:
-                    hits.append(self._draw(src, 0 if verdict.final_row == 0 else verdict.final_row + skip, temp, verdict.struck, torch_gen))
-            else:
-                hits = [self._draw(src, 0, temp, (), torch_gen)]
-            max_hit = len(hits) - 1
-            level_override = None
-            if phase == 2 and self.eos >= 0:                                      # filter_window on the new level (:578-580)
-                buf["am_host"].copy_(st.am[1:1 + W], non_blocking=True)
-                torch.cuda.current_stream().synchronize()
-                repl = [rng.choice(all_old_tokens) if tok == self.eos else -1 for tok in buf["am_host"].tolist()]
-                if any(x >= 0 for x in repl):
-                    override.copy_(torch.tensor(repl, dtype=torch.int32))
-                    level_override = override
-            forced.copy_(torch.tensor([max_hit, max_hit_idx] + hits + [0] * (cabi.MAX_LEVEL - len(hits)), dtype=torch.int32))
-            call("lade_greedy_post_step", ptr(st.ctl), ptr(st.window), st.wcap, ptr(st.pool_tok), ptr(st.pool_cnt), st.V, W, N, G,
-                 ptr(st.am), n_inp, ptr(st.guess), T, cand_rows, phase, int(self.pool_from_prompt), ptr(st.tail), self.eos,
-                 ptr(forced), ptr(level_override), ptr(st.record))
-            ops.kv_commit(e.kv, 0, 0, 0, ctl=st.ctl)
-            rec = st.read_record()
-            self.steps += 1
-            n_accept, eos_hit, self.g, self.P = rec[1], rec[2], rec[3], rec[4]
-            accepted = hits[:n_accept]
-            if on_step is not None:
-                on_step(accepted[:max(0, max_length - len(self.tokens))])
-            self.tokens += accepted
-            all_old_tokens += accepted
-            if phase != 2:
-                self.fill_level += 1
+            info = self.sample_step(keep_trace)
             if keep_trace:
-                trace.append(dict(T=T, P_before=P_before, max_hit=max_hit, max_hit_idx=max_hit_idx, accepted=list(accepted), phase=phase, **step_inputs))
-            if eos_hit or len(self.tokens) >= max_length:
+                trace.append(info)
+            if on_step is not None:
+                on_step(info["accepted"][:max(0, max_length - (len(self.tokens) - len(info["accepted"])))])
+            if self.finished_by_eos or len(self.tokens) >= max_length:
                 break
         generated = min(len(self.tokens), max_length) - len(self.prompt)
         out = GenOut(tokens=self.tokens[:max_length], steps=self.steps, generated=generated, trace=trace)
         if CONFIG_MAP.get("DEBUG", 0):
             CONFIG_MAP.setdefault("log", []).append([generated, self.steps, round(generated / self.steps, 2)])
         return out
+
+    @torch.no_grad()
+    @_on_device
+    def sample_step(self, keep_trace: bool = False) -> dict:
+        """One sampling step: model forward (eager or the forward-only hipGraph), device-side probability table, host-side
+        acceptance walk, one draw, device-side post-step."""
+        from .sampling import resolve_drafts
+        e, st = self.e, self.st
+        W, N, G, gs = self.W, self.N, self.G, self.gs
+        S = self._s
+        warp, fused_T, rng, torch_gen, all_old_tokens, forced, override = S["warp"], S["fused_T"], S["rng"], S["torch_gen"], S["old"], S["forced"], S["override"]
+        buf = self._sampling_buffers()
+        prompt_l, P, g, fill_level = self.prompt, self.P, self.g, self.fill_level
+        P_before = P
+        if self.steps == 0:
+            phase = 0
+            ids_h = prompt_l + self.window0
+            n_inp, cand_rows = len(self.window0), 0
+            logits, done = e.prefill(ids_h, [len(prompt_l) - 1] + list(range(len(prompt_l), len(ids_h))))
+            logits = logits.float()
+            ops.argmax_rows(logits, out=st.am)
+            T, P_before = len(ids_h) - done, done
+        elif self.use_graph and fill_level >= N - 2:
+            # steady step: input assembly + model step + argmax replayed as one hipGraph (candidate rows padded to the bucket)
+            if self._graph != "forward" or self._graph_gen != e.generation:
+                self._capture_graphs(forward_only=True)
+            phase, n_inp = 2, W
+            gcap = self._bucket_for(g)
+            T, cand_rows = self._graph_T[gcap], gcap * gs
+            if abs(e.n_splits_for(T, P + T) - self._graph_splits[gcap]) >= 2:
+                self._capture_graphs(forward_only=True)
+            if P + T > e.S_max:
+                raise cabi.LadeHipError(f"KV cache exhausted: P={P} + T={T} > S_max={e.S_max}")
+            self._graphs[gcap].replay()
+            logits = self._graph_logits[gcap]
+        else:
+            phase = 2 if fill_level >= N - 2 else 1
+            ls = self._level_sizes(fill_level)
+            cand_rows = g * gs if phase == 2 else 0
+            mask = StepMask.from_levels(1, ls, cand_rows, gs, P)
+            T = mask.T
+            call("lade_build_inputs", None, None, 1, ptr(st.window), st.wcap, ptr(st.ctl), min(fill_level, N - 2), 0, -1,
+                 ptr(st.guess), g if phase == 2 else 0, gs, cand_rows, ptr(st.ids), ptr(st.pos), None)
+            n_inp = ls[-1]
+            n_sel = self._set_sel([0] + list(range(T - cand_rows - n_inp, T - cand_rows)) + list(range(T - cand_rows, T)))
+            logits = e.forward(st.ids, st.pos, mask, st.sel, n_sel).float()    # logits.float(), modeling_llama.py:1544
+            ops.argmax_rows(logits, out=st.am)                                    # window levels are filled by argmax (:459, :545)
+        step_inputs = {}
+        if keep_trace and phase != 0:                            # what the step fed and judged (tests re-derive the probabilities)
+            step_inputs = dict(ids=st.ids[:T].tolist(), pos=st.pos[:T].tolist(), level_sizes=list(self._level_sizes(fill_level)),
+                               cand_rows=cand_rows, g=g, drafts=st.guess[:g * gs].tolist() if phase == 2 else [])
+        # ---- the step's token(s): rejection-sampling verify over the candidates, or a plain draw (:453-540) ----
+        verify = phase == 2 and g > 0
+        rows = 1 + g * gs if verify else 1
+        if fused_T is not None:                              # temperature only: the kernels scale the logits themselves
+            src, skip, temp = logits, n_inp, fused_T
+        else:                                                # top-k / top-p / HF warper objects: warped on the device by torch
+            picked = logits[0:1] if not verify else torch.cat([logits[0:1], logits[1 + n_inp:1 + n_inp + g * gs]])
+            src, skip, temp = warp(picked), 0, 1.0
+        max_hit_idx = 0
+        if verify:
+            ops.softmax_gather(src, rows, skip, st.guess, g, gs, max(G, 1), temp, buf["scal"], buf["stats"])
+            buf["scal_host"].copy_(buf["scal"], non_blocking=True)
+            buf["guess_host"].copy_(st.guess, non_blocking=True)
+            torch.cuda.current_stream().synchronize()                      # the step's one table read-back
+            table = buf["scal_host"].view(-1, max(G, 1))[:rows].tolist()
+            if keep_trace:
+                step_inputs["table"] = table
+            verdict = resolve_drafts(table, buf["guess_host"][:g * gs].tolist(), g, gs, rng.random)
+            hits, max_hit_idx = list(verdict.accepted), verdict.winner
+            if verdict.final_row is not None:
+                hits.append(self._draw(src, 0 if verdict.final_row == 0 else verdict.final_row + skip, temp, verdict.struck, torch_gen))
+        else:
+            hits = [self._draw(src, 0, temp, (), torch_gen)]
+        max_hit = len(hits) - 1
+        drawn_on_device = hits[-1] if torch.is_tensor(hits[-1]) else None
+        if drawn_on_device is not None:
+            hits[-1] = 0
+        level_override = None
+        if phase == 2 and self.eos >= 0:                                      # filter_window on the new level (:578-580)
+            buf["am_host"].copy_(st.am[1:1 + W], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            repl = [rng.choice(all_old_tokens) if tok == self.eos else -1 for tok in buf["am_host"].tolist()]
+            if any(x >= 0 for x in repl):
+                override.copy_(torch.tensor(repl, dtype=torch.int32))
+                level_override = override
+        forced.copy_(torch.tensor([max_hit, max_hit_idx] + hits + [0] * (cabi.MAX_LEVEL - len(hits)), dtype=torch.int32), non_blocking=True)
+        if drawn_on_device is not None:
+            forced[2 + max_hit:3 + max_hit].copy_(drawn_on_device)          # the drawn token never left the device
+        call("lade_greedy_post_step", ptr(st.ctl), ptr(st.window), st.wcap, ptr(st.pool_tok), ptr(st.pool_cnt), st.V, W, N, G,
+             ptr(st.am), n_inp, ptr(st.guess), T, cand_rows, phase, int(self.pool_from_prompt), ptr(st.tail), self.eos,
+             ptr(forced), ptr(level_override), ptr(st.record))
+        ops.kv_commit(e.kv, 0, 0, 0, ctl=st.ctl)
+        rec = st.read_record()
+        self.steps += 1
+        n_accept, eos_hit, self.g, self.P = rec[1], rec[2], rec[3], rec[4]
+        accepted = rec[8:8 + n_accept]                                     # = hits[:n_accept]; the record also carries a device-drawn token
+        self.tokens += accepted
+        all_old_tokens += accepted
+        if phase != 2:
+            self.fill_level += 1
+        self.finished_by_eos = bool(eos_hit)
+        return dict(T=T, P_before=P_before, max_hit=max_hit, max_hit_idx=max_hit_idx, accepted=list(accepted), phase=phase, g_next=self.g,
+                    P_after=self.P, **step_inputs)

@@ -88,7 +88,7 @@ class StepEngine:
     lade/models/modeling_llama.py:1448)."""
 
     def __init__(self, cfg: dict, weights: Dict[str, torch.Tensor], *, dtype=torch.bfloat16, device="cuda", max_seq: int = 4096,
-                 max_T: int = 512):
+                 max_T: int = 512, consume_weights: bool = False):
         cabi.load_library()                      # fail loudly when the HIP extension is missing
         if not torch.cuda.is_available():
             raise cabi.LadeHipError("StepEngine needs a GPU (MI355X); the HIP path has no CPU fallback")
@@ -105,11 +105,17 @@ class StepEngine:
         dev, dt = self.device, dtype
 
         def W(k):
-            return weights[k].to(device=dev, dtype=dt)
+            # consume_weights: the entry is removed from the caller's dict as soon as it has been fused into the engine's
+            # own layout, so a 140 GB model (Llama-2-70B in bf16) is never held twice
+            src = weights.pop(k) if consume_weights else weights[k]
+            return src.to(device=dev, dtype=dt)
 
+        tied = weights["lm_head"] is weights["embed"]
         self.embed = W("embed").contiguous()
         self.norm_w = W("norm").contiguous()
-        self.lm_head = W("lm_head").contiguous()
+        self.lm_head = self.embed if tied else W("lm_head").contiguous()
+        if tied and consume_weights:
+            weights.pop("lm_head", None)
         self.layers: List[dict] = []
         for i in range(self.L):
             p = f"layers.{i}."
