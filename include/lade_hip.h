@@ -29,6 +29,8 @@
  *   lade_window_fill_first / lade_window_fill / lade_window_roll   lade/decoding.py:1038-1066, :1119-1124
  *   lade_greedy_post_step    the fused single-rank tail of one steady step: verify + pool insert +
  *                            roll + next lookup + control update   lade/decoding.py:1071-1130,1165
+ *   lade_lp_unique_id / lade_lp_comm_create / lade_lp_allgather / lade_lp_comm_destroy   RCCL communicator + the step's one
+ *                            collective   lade/utils.py:28-33, lade/decoding.py:1024,1057,1090,1096,1106
  *   lade_lp_pack / lade_lp_reduce_apply   the per-step lookahead-parallel exchange record
  *                            lade/decoding.py:1023-1024, 1088-1107 (four pickled object collectives
  *                            -> one fixed int32 all-gather issued by the host through RCCL)
@@ -236,6 +238,21 @@ int lade_lp_reduce_apply(const int32_t* all_rec, int32_t R, int32_t rec_words, i
                          int32_t* window, int32_t wcap, int32_t* pool_tok, int32_t* pool_cnt, int32_t V, int32_t W,
                          int32_t N, int32_t G, int32_t phase, int32_t* guess_all, int32_t* scratch, int32_t* record,
                          int32_t pool_from_prompt, int32_t* tail, int32_t eos, void* stream);
+
+/* The step's one collective and its communicator: RCCL over xGMI, bound at run time by soname (the process
+ * keeps the RCCL instance it already carries, e.g. torch's).  Replaces dist.init_process_group (lade/utils.py:28-33) and the
+ * per-step object collectives of lade/decoding.py:1024, :1057, :1090, :1096, :1106 for a caller without torch.distributed.
+ *   lade_lp_unique_id    rank 0: 128 opaque bytes (ncclUniqueId) to hand to every rank over the host's own channel
+ *   lade_lp_comm_create  every rank, after hipSetDevice on its GPU; *comm_out = opaque handle, the only persistent allocation of
+ *                        the library; one handle per rank / process
+ *   lade_lp_allgather    recv[r*words .. ] = rank r's send[0..words): ordered on `stream` (after lade_lp_pack, before
+ *                        lade_lp_reduce_apply), in place allowed when send == recv + rank*words
+ *   lade_lp_comm_destroy explicit release
+ * Without an RCCL library in the process they return LADE_E_LIMIT. */
+int lade_lp_unique_id(void* id128);
+int lade_lp_comm_create(const void* id128, int32_t rank, int32_t world, void** comm_out);
+int lade_lp_allgather(void* comm, const int32_t* send, int32_t* recv, int32_t words_per_rank, void* stream);
+int lade_lp_comm_destroy(void* comm);
 
 /* ---- sampling helpers ------------------------------------------------------------------ */
 /* probs[r][:] = softmax(logits[r][:] / temperature) in fp32 */

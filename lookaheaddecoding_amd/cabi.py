@@ -70,6 +70,10 @@ SIGNATURES = {
                               _i32, _vp, _vp, _vp, _vp],
     "lade_lp_pack": [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp],
     "lade_lp_reduce_apply": [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp],
+    "lade_lp_unique_id": [_vp],
+    "lade_lp_comm_create": [_vp, _i32, _i32, C.POINTER(_vp)],
+    "lade_lp_allgather": [_vp, _vp, _vp, _i32, _vp],
+    "lade_lp_comm_destroy": [_vp],
     "lade_softmax_rows": [_vp, _i64, _i32, _i32, _i32, _f32, _vp, _vp],
     "lade_softmax_gather": [_vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "lade_rmsnorm": [_vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp],
@@ -136,6 +140,12 @@ def dtype_code(t: torch.Tensor) -> int:
         return DTYPE_CODE[t.dtype]
     except KeyError:
         raise LadeHipError(f"unsupported dtype {t.dtype}")
+
+
+def call_plain(name: str, *args) -> None:
+    """Invokes an entry point that takes no stream (communicator management) and raises on failure."""
+    fn = getattr(lib(), name)
+    check(fn(*args), name)
 
 
 def call(name: str, *args) -> None:

@@ -1,0 +1,109 @@
+// Lookahead parallelism over RCCL / xGMI behind the C ABI: an opaque communicator handle with explicit
+// create / destroy, and the one collective of a step - the all-gather of every rank's fixed int32 record.
+//
+// Replaces, for a caller that binds the C ABI without torch.distributed: the process-group init of lade/utils.py:28-33
+// (dist.init_process_group + torch.cuda.set_device) and the four pickled object collectives of a step
+// (lade/decoding.py:1024, :1057, :1090, :1096, :1106), which the record protocol folds into ONE ncclAllGather of
+// rec_words int32 per rank (tens of bytes: latency bound, issued on the step's own stream so that it is ordered with
+// lade_lp_pack before it and lade_lp_reduce_apply after it, and capturable with them).
+//
+// RCCL is bound at run time (dlopen by soname): a process that already carries an RCCL instance - torch ships one with the same
+// soname - keeps exactly that one, and a build box without RCCL still builds and loads the library (the entry points then fail
+// with LADE_E_LIMIT and a message).  The unique id travels between the ranks by whatever channel the host already has
+// (the reference: the TCP store behind init_process_group); rank 0 obtains it from lade_lp_unique_id.
+#include <dlfcn.h>
+#include <string.h>
+
+#include "common.hpp"
+
+namespace {
+
+typedef int ncclResult_t;                      // ncclSuccess == 0
+typedef struct { char internal[128]; } ncclUniqueId;      // NCCL_UNIQUE_ID_BYTES
+typedef void* ncclComm_t;
+constexpr int ncclInt32 = 2;                   // ncclDataType_t: ncclInt8 0, ncclUint8 1, ncclInt32 2
+
+struct Rccl {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+
+Rccl& rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r;
+    tried = true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);       // an instance the process already carries (torch's) wins
+        if (r.h) break;
+    }
+    for (int i = 0; !r.h && i < 3; ++i) r.h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+    if (!r.h) return r;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
+    r.AllGather = (decltype(r.AllGather))dlsym(r.h, "ncclAllGather");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+    r.ok = r.GetUniqueId && r.CommInitRank && r.AllGather && r.CommDestroy;
+    return r;
+}
+
+struct LpComm {
+    ncclComm_t comm;
+    int rank, world;
+};
+
+const char* err_text(Rccl& r, ncclResult_t e) { return r.GetErrorString ? r.GetErrorString(e) : "rccl error"; }
+
+}  // namespace
+
+#define RCCL_OR_FAIL(what)                                                                                     \
+    Rccl& R = rccl();                                                                                          \
+    LADE_REQUIRE(R.ok, LADE_E_LIMIT, what ": RCCL (librccl.so.1) is not available in this process: %s", dlerror() ? dlerror() : "missing symbols")
+
+extern "C" int lade_lp_unique_id(void* id128) {
+    LADE_REQUIRE(id128, LADE_E_ARG, "lade_lp_unique_id: null buffer");
+    RCCL_OR_FAIL("lade_lp_unique_id");
+    ncclUniqueId id;
+    const ncclResult_t e = R.GetUniqueId(&id);
+    LADE_REQUIRE(e == 0, LADE_E_LAUNCH, "lade_lp_unique_id: %s", err_text(R, e));
+    memcpy(id128, &id, sizeof(id));
+    return LADE_OK;
+}
+
+extern "C" int lade_lp_comm_create(const void* id128, int32_t rank, int32_t world, void** comm_out) {
+    LADE_REQUIRE(id128 && comm_out && world >= 1 && rank >= 0 && rank < world, LADE_E_ARG, "lade_lp_comm_create: rank=%d world=%d", rank, world);
+    RCCL_OR_FAIL("lade_lp_comm_create");
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclComm_t c = nullptr;
+    const ncclResult_t e = R.CommInitRank(&c, world, id, rank);      // binds to the calling thread's current HIP device (lade/utils.py:32)
+    LADE_REQUIRE(e == 0 && c, LADE_E_LAUNCH, "lade_lp_comm_create: ncclCommInitRank: %s", err_text(R, e));
+    *comm_out = new LpComm{c, rank, world};
+    return LADE_OK;
+}
+
+extern "C" int lade_lp_allgather(void* comm, const int32_t* send, int32_t* recv, int32_t words_per_rank, void* stream) {
+    LADE_REQUIRE(comm && send && recv && words_per_rank > 0, LADE_E_ARG, "lade_lp_allgather: bad args (words=%d)", words_per_rank);
+    RCCL_OR_FAIL("lade_lp_allgather");
+    LpComm* lc = (LpComm*)comm;
+    const ncclResult_t e = R.AllGather(send, recv, (size_t)words_per_rank, ncclInt32, lc->comm, (hipStream_t)stream);
+    LADE_REQUIRE(e == 0, LADE_E_LAUNCH, "lade_lp_allgather: %s", err_text(R, e));
+    return LADE_OK;
+}
+
+extern "C" int lade_lp_comm_destroy(void* comm) {
+    if (!comm) return LADE_OK;
+    RCCL_OR_FAIL("lade_lp_comm_destroy");
+    LpComm* lc = (LpComm*)comm;
+    const ncclResult_t e = R.CommDestroy(lc->comm);
+    delete lc;
+    LADE_REQUIRE(e == 0, LADE_E_LAUNCH, "lade_lp_comm_destroy: %s", err_text(R, e));
+    return LADE_OK;
+}

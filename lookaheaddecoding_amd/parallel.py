@@ -19,6 +19,7 @@ test-only backend stands in for the HIP kernels; the product backend is `HipLPBa
 """
 from __future__ import annotations
 
+import os
 import random
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
@@ -64,6 +65,40 @@ def shard_level_sizes(level_lens: Sequence[int], c0: int, c1: int) -> List[int]:
 def rec_words(gs: int, wcap: int, G: int = 0) -> int:
     """int32 words of one rank's record: head | new window tokens [wcap] | argmax ids of its candidate rows [<= G*gs]"""
     return REC_HEAD + wcap + max(G, 0) * gs
+
+
+class RcclComm:
+    """The C ABI's own communicator (lade_lp_comm_create / lade_lp_allgather / lade_lp_comm_destroy): what a caller without
+    torch.distributed binds.  The 128-byte unique id is produced on rank 0 and handed to the other ranks by `exchange_id`
+    (any host channel; here torch.distributed's store when a process group exists, nothing for a single rank)."""
+
+    def __init__(self, rank: int, world: int, exchange_id=None):
+        import ctypes as C
+        from . import cabi
+        self._cabi, self.rank, self.world = cabi, rank, world
+        buf = (C.c_char * 128)()
+        if rank == 0:
+            cabi.call_plain("lade_lp_unique_id", buf)
+        ident = bytes(buf)
+        if world > 1:
+            if exchange_id is None:
+                def exchange_id(b):
+                    box = [b if rank == 0 else None]
+                    dist.broadcast_object_list(box, src=0)
+                    return box[0]
+            ident = exchange_id(ident)
+        handle = C.c_void_p()
+        cabi.call_plain("lade_lp_comm_create", C.create_string_buffer(ident, 128), rank, world, C.byref(handle))
+        self.handle = handle
+
+    def all_gather(self, out: torch.Tensor, inp: torch.Tensor) -> None:
+        assert out.dtype == torch.int32 and inp.dtype == torch.int32 and out.numel() == self.world * inp.numel()
+        self._cabi.call("lade_lp_allgather", self.handle, self._cabi.ptr(inp), self._cabi.ptr(out), inp.numel())
+
+    def close(self) -> None:
+        if self.handle is not None:
+            self._cabi.call_plain("lade_lp_comm_destroy", self.handle)
+            self.handle = None
 
 
 class HipLPBackend:
@@ -130,9 +165,19 @@ class HipLPBackend:
     def new_gather_buffer(self, R: int) -> torch.Tensor:
         return torch.zeros(R * self.rw, dtype=torch.int32, device=self.device)
 
+    comm = None          # RcclComm when the step's collective goes through the C ABI (set by LPRunner)
+
     def broadcast_window(self, window0: List[int], lp: LPContext) -> List[int]:
+        """rank 0's random window reaches every rank (lade/decoding.py:905-906)"""
+        if lp.R == 1:
+            return list(window0)
         t = torch.tensor(window0, dtype=torch.int32, device=self.device)
-        dist.broadcast(t, src=0, group=lp.group)
+        if self.comm is not None:                       # no torch.distributed in play: gather everybody's window, keep rank 0's
+            allw = torch.zeros(lp.R * t.numel(), dtype=torch.int32, device=self.device)
+            self.comm.all_gather(allw, t)
+            t = allw[:t.numel()]
+        else:
+            dist.broadcast(t, src=0, group=lp.group)
         self.sync_gemm_choice(lp)
         return t.tolist()
 
@@ -156,12 +201,22 @@ class LPRunner:
     def __init__(self, dec, backend=None, all_gather=None):
         self.dec = dec
         self.lp: LPContext = dec.lp
-        # the collective is injectable so that tests can run several ranks inside one process
-        self.all_gather = all_gather if all_gather is not None else (lambda out, inp: dist.all_gather_into_tensor(out, inp, group=self.lp.group))
+        # the collective is injectable so that tests can run several ranks inside one process.  Default: torch.distributed's
+        # all_gather_into_tensor (RCCL); LADE_LP_COLLECTIVE=abi routes it through the C ABI's own communicator
+        # (lade_lp_allgather) instead - the path a caller without torch.distributed uses.
+        if all_gather is None:
+            if os.environ.get("LADE_LP_COLLECTIVE", "torch") == "abi":
+                self.comm = RcclComm(self.lp.rank, self.lp.R)
+                all_gather = self.comm.all_gather
+            else:
+                all_gather = lambda out, inp: dist.all_gather_into_tensor(out, inp, group=self.lp.group)
+        self.all_gather = all_gather
         self.W, self.N, self.G = dec.W, dec.N, dec.G
         if self.lp.R > self.W:
             raise ValueError(f"lookahead parallelism needs DIST_WORKERS ({self.lp.R}) <= WINDOW_SIZE ({self.W})")
         self.be = backend if backend is not None else HipLPBackend(dec)
+        if getattr(self, "comm", None) is not None:
+            self.be.comm = self.comm
 
     def start(self, prompt: Sequence[int], eos_token_id: Optional[int] = None, rng: Optional[random.Random] = None) -> None:
         rng = rng if rng is not None else random

@@ -126,3 +126,39 @@ def test_lp_single_rank_over_rccl():
         assert out.tokens == run["tokens"] and out.steps == run["steps"]
     finally:
         dist.destroy_process_group()
+
+
+def test_lp_collective_through_the_c_abi_single_rank():
+    """lade_lp_unique_id / lade_lp_comm_create / lade_lp_allgather / lade_lp_comm_destroy on a real 1-rank RCCL communicator, and a
+    whole greedy run whose per-step collective goes through it (LADE_LP_COLLECTIVE=abi): tokens and step count of the reference."""
+    from lookaheaddecoding_amd import parallel
+    from lookaheaddecoding_amd.decoding import LookaheadDecoder
+    from lookaheaddecoding_amd.engine import StepEngine
+    torch.cuda.set_device(0)
+    comm = parallel.RcclComm(0, 1)
+    src = torch.arange(37, dtype=torch.int32, device="cuda") * 3 + 1
+    dst = torch.zeros(37, dtype=torch.int32, device="cuda")
+    comm.all_gather(dst, src)
+    torch.cuda.synchronize()
+    assert torch.equal(dst, src)
+    g = torch.cuda.CUDAGraph()                      # the collective is ordered on the step's stream and can be captured with it
+    src2 = src.clone()
+    with torch.cuda.graph(g):
+        comm.all_gather(dst, src2)
+    src2 += 5
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(dst, src + 5)
+    comm.close()
+    with open(os.path.join(GOLDEN, "e2e_greedy.json")) as f:
+        run = json.load(f)["runs"][1]
+    cfg = make_config(run["model"], max_pos=512)
+    w = {k: torch.as_tensor(v) for k, v in random_weights_numpy(cfg, seed=run["model_seed"], std=run["std"]).items()}
+    eng = StepEngine(cfg, w, dtype=torch.float32, max_seq=512, max_T=320)
+    dec = LookaheadDecoder(eng, run["W"], run["N"], run["G"], lp=parallel.LPContext(rank=0, world=1), pool_from_prompt=bool(run["pool_from_prompt"]))
+    os.environ["LADE_LP_COLLECTIVE"] = "abi"
+    try:
+        out = parallel.greedy_lp(dec, run["prompt"], run["max_length"], eos_token_id=run["eos"], rng=random.Random(run["seed"]))
+    finally:
+        os.environ.pop("LADE_LP_COLLECTIVE", None)
+    assert out.tokens == run["tokens"] and out.steps == run["steps"]
