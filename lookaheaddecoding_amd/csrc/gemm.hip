@@ -1,4 +1,5 @@
-// Skinny weight-streaming GEMM for the decode step:  C[M,N] = A[M,K] . W[N,K]^T,  M <= 128 per row block.
+// Skinny weight-streaming GEMM for the decode step:  C[M,N] = A[M,K] . W[N,K]^T,  M <= 256 per row block (a work-group holds every
+// activation row of the step, so the weights are streamed once whatever M is).
 //
 // Reference: the nn.Linear projections of the step (q/k/v/o, gate/up/down, lm_head;
 // lade/models/modeling_llama.py:360-380, 492-494, 558, 1541) - SURVEY.md 8(f) rank 2.  With M = T <= 240 rows
@@ -256,9 +257,11 @@ extern "C" int lade_gemm_skinny(const void* A, int64_t lda, const void* W, int64
                  "lade_gemm_skinny: K=%d must be a multiple of %d, strides / N multiples of 8", K, G_BK);
     LADE_REQUIRE(n_split == 1 ? (C != nullptr && ldc % 8 == 0) : (Cpart != nullptr), LADE_E_ARG, "lade_gemm_skinny: missing output buffer");
     LADE_REQUIRE(dtype == LADE_BF16 || dtype == LADE_F16, LADE_E_DTYPE, "lade_gemm_skinny: dtype=%d", dtype);
-    if (mb == 0) mb = M <= 32 ? 1 : (M <= 64 ? 2 : (M <= 96 ? 3 : 4));
-    if (mt == 0) mt = 1;
-    LADE_REQUIRE(mb >= 1 && mb <= 4 && mt >= 1 && mt <= 4 && mb % mt == 0, LADE_E_ARG, "lade_gemm_skinny: mb=%d mt=%d", mb, mt);
+    if (mb == 0) mb = M <= 32 ? 1 : (M <= 64 ? 2 : (M <= 96 ? 3 : (M <= 128 ? 4 : (M <= 192 ? 6 : 8))));
+    if (mt == 0) mt = mb <= 4 ? 1 : mb / 2;
+    if (mb > 4 && nt == 0) nt = 1;
+    LADE_REQUIRE(mb >= 1 && mb <= 8 && mt >= 1 && mt <= 4 && mb % mt == 0, LADE_E_ARG, "lade_gemm_skinny: mb=%d mt=%d", mb, mt);
+    if (mb > 4 && bn > 128) bn = 128;      // 192 / 256-row work-groups: the activation tile leaves room for <= 128 weight rows per stage
     const int mw = mb / mt;
     const int tiles = bn <= 32 ? 1 : (bn <= 64 ? 2 : (bn <= 128 ? 4 : (bn <= 192 ? 6 : 8)));      // 32-row weight tiles per work-group
     if (nt == 0) {                                     // default: as many n-groups as waves allow
@@ -283,7 +286,9 @@ extern "C" int lade_gemm_skinny(const void* A, int64_t lda, const void* W, int64
                    SHAPE(TT,1,3,4,1) SHAPE(TT,1,3,6,1) SHAPE(TT,1,3,8,1) SHAPE(TT,1,3,3,2) SHAPE(TT,1,3,4,2)                    \
     /* 128 rows */ SHAPE(TT,4,1,1,1) SHAPE(TT,4,1,2,1) SHAPE(TT,4,1,2,2) SHAPE(TT,4,1,2,3) SHAPE(TT,4,1,2,4)                    \
                    SHAPE(TT,2,2,2,1) SHAPE(TT,2,2,4,1) SHAPE(TT,2,2,3,2) SHAPE(TT,2,2,4,2) SHAPE(TT,2,2,2,2)                    \
-                   SHAPE(TT,1,4,4,1) SHAPE(TT,1,4,6,1) SHAPE(TT,1,4,8,1) SHAPE(TT,1,4,3,2) SHAPE(TT,1,4,4,2) SHAPE(TT,1,4,2,2)
+                   SHAPE(TT,1,4,4,1) SHAPE(TT,1,4,6,1) SHAPE(TT,1,4,8,1) SHAPE(TT,1,4,3,2) SHAPE(TT,1,4,4,2) SHAPE(TT,1,4,2,2)                    \
+    /* 192 rows */ SHAPE(TT,2,3,2,1) SHAPE(TT,2,3,4,1) SHAPE(TT,2,3,2,2) SHAPE(TT,3,2,2,1) SHAPE(TT,3,2,2,2)                                     \
+    /* 256 rows */ SHAPE(TT,2,4,2,1) SHAPE(TT,2,4,4,1) SHAPE(TT,2,4,2,2) SHAPE(TT,4,2,2,1) SHAPE(TT,4,2,2,2)
     if (dtype == LADE_BF16) { GO(BF16) } else { GO(F16) }
 #undef GO
 #undef SHAPE

@@ -217,7 +217,7 @@ class StepEngine:
         """(mb, bn, n_split, mt, nt) of the split-K GEMM for projection `name` at a step of M rows, or None when the library
         GEMM is faster.  Timed once per (projection, row class) on this GPU, rotating through the layers' weights so the
         stream comes from HBM rather than from the Infinity Cache."""
-        mclass = 32 if M <= 32 else (64 if M <= 64 else (96 if M <= 96 else 128))
+        mclass = next(c for c in self.ROW_CLASSES if M <= c)
         key = (name, mclass)
         if key in self.gemm_cfg:
             return self.gemm_cfg[key]
@@ -236,19 +236,23 @@ class StepEngine:
         return best
 
     def _tune_timed(self, name: str, mclass: int, ws, N: int, K: int):
-        a = torch.randn({32: 30, 64: 60, 96: 92, 128: 128}[mclass], K, device=self.device).to(self.dtype)
+        a = torch.randn({32: 30, 64: 60, 96: 92, 128: 128, 192: 180, 256: 240}[mclass], K, device=self.device).to(self.dtype)
         out = torch.empty(a.shape[0], N, dtype=self.dtype, device=self.device)
         cands = []
         # (m-blocks per work-group, m-blocks per wave, n-tiles per wave (0 = fewest), weight rows per work-group)
         shapes = {32: ((1, 1, 0, (64, 128, 256)), (1, 1, 2, (128, 256)), (2, 1, 0, (128,))),
                   64: ((2, 1, 0, (128, 256)), (2, 2, 0, (128, 192, 256)), (2, 2, 2, (192, 256))),
                   96: ((3, 1, 0, (64, 128, 192, 256)), (3, 3, 0, (128, 192, 256)), (3, 3, 2, (192, 256)), (4, 1, 0, (128, 192)), (4, 2, 0, (128, 192))),
-                  128: ((4, 1, 0, (64, 128, 192, 256)), (4, 2, 0, (128, 192, 256)), (4, 4, 0, (192, 256)), (4, 4, 2, (192, 256)))}[mclass]
+                  128: ((4, 1, 0, (64, 128, 192, 256)), (4, 2, 0, (128, 192, 256)), (4, 4, 0, (192, 256)), (4, 4, 2, (192, 256))),
+                  # 192 / 256 rows (config 4's 120 + 6g-token steps, hot-regime steps): the activation tile alone is 24 / 32 KB per stage,
+                  # so the weight tile stays at <= 128 rows for the 3-stage ring to fit the 160 KB of LDS
+                  192: ((6, 3, 1, (64, 128)), (6, 3, 2, (128,)), (6, 2, 1, (64,)), (6, 2, 2, (128,))),
+                  256: ((8, 4, 1, (64, 128)), (8, 4, 2, (128,)), (8, 2, 1, (64,)), (8, 2, 2, (128,)))}[mclass]
         for mb, mt, nt, bns in shapes:
             for bn in bns:
                 nblk = (N + bn - 1) // bn
                 for S in sorted({max(1, round(self.n_cu / nblk)), max(1, round(self.n_cu * 2 / nblk)), max(1, round(self.n_cu * 3 / nblk))}):
-                    if 2 <= S <= 16 and K // 64 >= 2 * S:
+                    if 2 <= S <= 16 and K // 64 >= 2 * S and S * a.shape[0] <= 16 * 128:       # the partial workspace holds 16 x 128 rows
                         cands.append((mb, bn, S, mt, nt))
 
         def time_it(fn, reps=16):
@@ -275,13 +279,14 @@ class StepEngine:
         return best
 
     GEMM_NAMES = ("wqkv", "wo", "wgu", "wd")
+    ROW_CLASSES = (32, 64, 96, 128, 192, 256)
 
     def tune_all(self) -> dict:
         """Every (projection, row class) decision of this engine as a plain dict (lookahead parallelism: rank 0 tunes,
         the other ranks adopt its table through `adopt_gemm_cfg`, so that all replicas round alike)."""
         if not self.custom_gemm:
             return {}
-        return {f"{n}:{m}": self._tune(n, m) for n in self.GEMM_NAMES for m in (32, 64, 96, 128)}
+        return {f"{n}:{m}": self._tune(n, m) for n in self.GEMM_NAMES for m in self.ROW_CLASSES}
 
     def adopt_gemm_cfg(self, table: dict) -> None:
         for k, v in table.items():
@@ -304,7 +309,7 @@ class StepEngine:
         if n_splits is None:
             n_splits = self.n_splits_for(T, P + T)
         ops.gather_rows(self.embed, ids, out=x, rows=T)
-        fused = self.custom_gemm and T <= 128
+        fused = self.custom_gemm and T <= self.ROW_CLASSES[-1]
         cfg_qkv = self._tune("wqkv", T) if fused else None
         cfg_o = self._tune("wo", T) if fused else None
         cfg_gu = self._tune("wgu", T) if fused else None
