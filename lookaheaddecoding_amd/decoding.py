@@ -115,7 +115,16 @@ class LookaheadDecoder:
         return [W + N - 3 - fill_level] + [W + N - 2 - fill_level] * fill_level
 
     def _set_sel(self, rows: List[int]) -> int:
-        self.st.sel[:len(rows)].copy_(torch.tensor(rows, dtype=torch.int32), non_blocking=True)
+        """Device copy of the logits-row selection.  The selections of a run are a handful of shapes (one per phase / candidate
+        count), so each is uploaded once and kept: a steady eager step issues no host-to-device copy for it."""
+        key = (rows[0], rows[1] if len(rows) > 1 else -1, len(rows), rows[-1])
+        cache = self.__dict__.setdefault("_sel_cache", {})
+        t = cache.get(key)
+        if t is None:
+            if len(cache) > 256:
+                cache.clear()
+            t = cache[key] = torch.tensor(rows, dtype=torch.int32, device=self.e.device)
+        self.st.sel[:len(rows)].copy_(t, non_blocking=True)
         return len(rows)
 
     # ---- stepwise API (bench.py drives single steps; greedy() is start + step until done) ----------

@@ -148,7 +148,7 @@ class HipLPBackend:
                  guess_ptr, g_local if phase == 2 else 0, gs, cand_rows, ptr(st.ids), ptr(st.pos), None)
             n_inp = ls[-1]
             rows = [n_input - 1] + list(range(T - cand_rows - n_inp, T - cand_rows)) + list(range(T - cand_rows, T))
-            st.sel[:len(rows)].copy_(torch.tensor(rows, dtype=torch.int32))
+            d._set_sel(rows)                 # cached on the device per shape: no host-to-device copy in a steady step
             logits = e.forward(st.ids, st.pos, mask, st.sel, len(rows))
         self.ops.argmax_rows(logits, out=st.am)
         am = st.am.data_ptr()

@@ -1,0 +1,48 @@
+"""GPU: the two application-level scripts kept from the reference run end to end on the drop-in surface:
+examples/minimal.py (reference: minimal.py:29-52) and examples/eval_synthetic.py (reference: applications/eval_mtbench.py:267-386)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import ROOT
+
+
+def _run(args, env_extra, timeout=600):
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-3000:]
+    return r.stdout
+
+
+def test_minimal_example_lookahead_equals_plain_hf_fp32():
+    out = _run(["examples/minimal.py", "--shape", "tiny-d64", "--dtype", "float32", "--max-new-tokens", "48", "--level", "4", "--window", "5", "--guess", "5"],
+               {"LOAD_LADE": "1", "USE_LADE": "1"})
+    assert "Greedy Generated Tokens: 48" in out and "Sample Generated Tokens: 48" in out
+    assert "LADE LOG - OVERALL GEN:" in out
+    assert "lookahead greedy ids identical: True" in out, out[-800:]
+
+
+def test_eval_harness_writes_answers_stats_and_log(tmp_path):
+    ans = str(tmp_path / "answers" / "synthetic.jsonl")
+    out = _run(["examples/eval_synthetic.py", "--answer-file", ans, "--shape", "tiny-d64", "--dtype", "float32", "--questions", "3", "--max-new-token", "24",
+                "--level", "4", "--window", "5", "--guess", "5"], {"USE_LADE": "1"})
+    recs = [json.loads(l) for l in open(ans)]
+    assert [r["question_id"] for r in recs] == [81, 82, 83]
+    for r in recs:
+        assert set(r) == {"question_id", "answer_id", "model_id", "choices", "tstamp"}
+        ch = r["choices"][0]
+        assert ch["index"] == 0 and len(ch["turns"]) == 2 and len(ch["prompts"]) == 2
+        assert all(len(t) == 24 for t in ch["turns"])
+        assert ch["prompts"][1][:len(ch["prompts"][0])] == ch["prompts"][0]           # the second prompt continues the conversation
+        assert ch["prompts"][1][len(ch["prompts"][0]):len(ch["prompts"][0]) + 24] == ch["turns"][0]
+    stats = torch.load(ans + ".pt")
+    assert set(stats) == {0, 1} and all(len(v) == 2 and v[1] == 24 for v in stats.values())
+    log = torch.load(ans + "-lade-log.pt")
+    assert len(log) == 6 and all(e[0] == 24 and e[1] <= 24 for e in log)          # [generated, steps, ratio] per generate call
+    assert "AVERAGE THROUGHPUT1" in out and "LADE LOG - OVERALL GEN:  144" in out

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--reps", type=int, default=400)
     ap.add_argument("--resident", action="store_true", help="one K/V cache, re-read every repetition (stays in the Infinity Cache)")
+    ap.add_argument("--lp-rank", action="store_true", help="a lookahead-parallel rank's step instead of the full window: 4 re-fed inputs, "
+                    "columns 12..14 of the W=15 window, 2 candidates (T = 31; with --H 64 --Hkv 8 this is config 5's rank shape)")
     a = ap.parse_args()
     W, N = 15, 5
     gs = N - 1
@@ -35,6 +37,10 @@ def main():
             k = [torch.randn(a.Hkv, S_max, a.d, device="cuda").bfloat16() for _ in range(n_rot)]
             vt = [torch.randn(a.Hkv, a.d, S_max, device="cuda").bfloat16() for _ in range(n_rot)]
             mask = ops.StepMask.from_levels(1, [W - 1] + [W] * (N - 2), g * gs, gs, P)
+            if a.lp_rank:
+                mask = ops.StepMask.from_levels(4, [13, 2, 2, 2], 8, gs, P)
+                T = mask.T
+                q = torch.randn(T, (a.H + 2 * a.Hkv) * a.d, device="cuda").bfloat16()
             alg = 2 * (2 * a.Hkv * (P + T) * a.d + 2 * a.H * T * a.d)
             for ns in a.splits:
                 n = ns if ns > 0 else ops.choose_splits(a.H, a.H // a.Hkv, T, P + T)

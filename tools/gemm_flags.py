@@ -11,6 +11,8 @@ from lookaheaddecoding_amd.cabi import call, dtype_code, ptr
 
 M = int(os.environ.get("M", "60"))
 CFG = {"qkv": (12288, 4096, 2, 2, 192, 0, 4), "o": (4096, 4096, 2, 2, 128, 0, 8), "gate_up": (22016, 4096, 2, 2, 192, 0, 4), "down": (4096, 11008, 2, 1, 128, 0, 8)}
+if M > 64:      # the 128-row class: four m-blocks, two per wave
+    CFG = {"qkv": (12288, 4096, 4, 2, 192, 0, 4), "o": (4096, 4096, 4, 2, 128, 0, 8), "gate_up": (22016, 4096, 4, 2, 192, 0, 4), "down": (4096, 11008, 4, 2, 128, 0, 8)}
 
 
 def timeit(fn, reps=40, rounds=5):
