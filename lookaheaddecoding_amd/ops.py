@@ -65,8 +65,12 @@ def choose_splits(H: int, n_rep: int, T: int, S_tot: int, n_cu: int = 256, allow
     fill = max(1, n_cu // max(blocks, 1))
     if forced == 1:
         return max(1, min(fill, tiles, 32))
-    # streaming time per work-group falls as tiles/splits, the merge (and the partial round trip) grows with splits
-    return max(1, min(fill, max(2, tiles // 2), tiles, 32))
+    # streaming time per work-group falls as tiles/splits, the merge (and the partial round trip) grows with splits: the measured
+    # optimum follows sqrt(tiles) - 5 splits at 18 tiles, 6 at 34, 8 at 65 (round 2, isolated pair at 34 tiles: 16.8 us with 6
+    # splits, 17.1 us with 8)
+    want = max(1, min(fill, math.isqrt(max(tiles - 1, 0)) + 1, tiles, 32))
+    tps = (tiles + want - 1) // want              # tiles per split
+    return (tiles + tps - 1) // tps               # drop the splits that would be empty
 
 
 def attn_fwd(q: torch.Tensor, k_cache: torch.Tensor, vt_cache: torch.Tensor, mask: StepMask, *, H: int, Hkv: int, d: int,

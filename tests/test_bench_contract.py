@@ -7,7 +7,7 @@ from conftest import ROOT
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    with open(os.path.join(ROOT, "profiles", "r1_bench.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r2_bench.json")) as f:
         line = [l for l in f.read().splitlines() if l.strip().startswith("{")][-1]
     d = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):

@@ -14,9 +14,9 @@ run() {   # label, counters, command...
     local f=$(find /tmp/prof_$label -name "*counter_collection.csv" | head -1)
     [ -n "$f" ] && cp "$f" $OUT/$label.csv || echo "no counter csv for $label"
 }
-A7="python $ROOT/tools/attn_bench.py --T 60 --P 2016 --splits 8 --reps 40"
-A7B="python $ROOT/tools/attn_bench.py --T 120 --P 2016 --splits 8 --reps 40"
-A70="python $ROOT/tools/attn_bench.py --lp-rank --H 64 --Hkv 8 --P 2016 --splits 8 --reps 40"
+A7="python $ROOT/tools/attn_bench.py --T 60 --P 2016 --splits 0 --reps 40"
+A7B="python $ROOT/tools/attn_bench.py --T 120 --P 2016 --splits 0 --reps 40"
+A70="python $ROOT/tools/attn_bench.py --lp-rank --H 64 --Hkv 8 --P 2016 --splits 0 --reps 40"
 G128="env M=128 python $ROOT/tools/gemm_flags.py"
 G60="env M=60 python $ROOT/tools/gemm_flags.py"
 MF="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"

@@ -42,5 +42,5 @@ for label, path in files:
         with open(os.path.join(trim, os.path.basename(path)), "w", newline="") as f:
             wr = csv.writer(f)
             wr.writerow(["Dispatch_Id", "Kernel", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"])
-            wr.writerows(rows[:2000])
+            wr.writerows(rows[:480])
 json.dump(doc, open(out, "w"), indent=1)
