@@ -246,3 +246,25 @@ def test_sampling_logits_within_tolerance_bf16():
     assert torch.allclose(logits[0], ref.out_logits, atol=6e-2, rtol=5e-2)
     assert torch.allclose(logits[T - lay.lguess - W:T - lay.lguess], ref.inp_logits, atol=6e-2, rtol=5e-2)
     assert torch.allclose(logits[T - lay.lguess:], ref.guess_logits, atol=6e-2, rtol=5e-2)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_cache_exhaustion_raises_and_never_writes_past_the_cache(use_graph):
+    """A tightly sized KV cache: the run must end with LadeHipError when a step no longer fits - in hipGraph mode too, where the
+    capture warm-up runs whole step bodies at the current cache length and the kernels read the length from the device - and
+    everything decoded before that must still be the plain greedy stream (no K/V row was written over a neighbouring head)."""
+    from lookaheaddecoding_amd import cabi
+    from lookaheaddecoding_amd.decoding import LookaheadDecoder
+    from lookaheaddecoding_amd.engine import StepEngine
+    cfg = make_config("tiny-d128", max_pos=512)
+    w = {k: torch.as_tensor(v) for k, v in random_weights_numpy(cfg, seed=2, std=0.05).items()}
+    eng = StepEngine(cfg, w, dtype=torch.float32, max_seq=128, max_T=64)
+    assert eng.S_max == 128
+    prompt = [1, 5, 9, 17, 33, 5, 9, 17, 44, 5, 9] * 3
+    dec = LookaheadDecoder(eng, 5, 4, 5, pool_from_prompt=True, use_graph=use_graph)
+    with pytest.raises(cabi.LadeHipError, match="exhausted|exceeds"):
+        dec.greedy(prompt, 400, rng=random.Random(2))
+    got = list(dec.tokens)
+    assert len(got) > len(prompt) + 40                      # it ran until the cache was nearly full
+    big = StepEngine(cfg, w, dtype=torch.float32, max_seq=512, max_T=64)
+    assert big.plain_greedy(prompt, len(got)) == got
