@@ -266,7 +266,7 @@ def worker(args):
     if use_lp:
         from lookaheaddecoding_amd.parallel import LPContext
         lp = LPContext(rank=rank, world=world)
-    dec = LookaheadDecoder(eng, W, N, G, lp=lp, use_graph=not args.no_graph and not use_lp)
+    dec = LookaheadDecoder(eng, W, N, G, lp=lp, use_graph=not args.no_graph)      # LP: the rank-local part of a steady step is a hipGraph segment
     prompt = torch.randint(3, cfg["vocab"], (args.prompt_len,), generator=torch.Generator().manual_seed(123)).tolist()
 
     def sync():

@@ -170,11 +170,13 @@ int lade_kv_commit(void* cache, int64_t layer_stride, int64_t v_offset, int32_t 
  * positions = the n_input positions ending at ctl[LADE_CTL_LST_POS].  (c0,c1) = this rank's window columns under lookahead
  * parallelism (lade/decoding.py:973-984), c1 < 0 = all columns.  g < 0 reads ctl[LADE_CTL_G].
  * cand_rows >= 0 emits exactly that many candidate rows (zero tokens beyond g*gs: fixed-shape graph
- * replay), cand_rows < 0 emits g*gs.  out_T[0] = total tokens written (may be null). */
+ * replay), cand_rows < 0 emits g*gs.  out_T[0] = total tokens written (may be null).  lp_world > 1 with g < 0: the candidates
+ * emitted are rank lp_rank's share of ctl[LADE_CTL_G] (lade/decoding.py:956-963), decided on the device; otherwise pass 0, 1. */
 int lade_build_inputs(const int32_t* in_ids, const int32_t* in_pos, int32_t n_input, const int32_t* window,
                       int32_t wcap, const int32_t* ctl, int32_t fill_level, int32_t c0, int32_t c1,
                       const int32_t* guess, int32_t g, int32_t gs, int32_t cand_rows, int32_t* ids, int32_t* pos,
-                      int32_t* out_T, void* stream);
+                      int32_t* out_T, int32_t lp_rank, int32_t lp_world,
+                      void* stream);
 
 /* one argmax per row, first index wins ties (torch.argmax semantics); logits [rows][V] with row
  * stride `ld` elements. */
@@ -231,9 +233,11 @@ int lade_greedy_post_step(int32_t* ctl, int32_t* window, int32_t wcap, int32_t* 
  * (lade/decoding.py:1024, :1071-1096) - so every rank takes the same decision even when 16-bit logits round
  * differently from rank to rank.  scratch: int32[R*split + G*gs].  pool_from_prompt / tail / eos: as in
  * lade_greedy_post_step (the EOS scan and the POOL_FROM_PROMPT appends of lade/decoding.py:1167-1177 run identically on
- * every rank); record[1] = n_accept, record[2] = finished, record[5] = winning rank. */
+ * every rank); record[1] = n_accept, record[2] = finished, record[5] = winning rank.  lade_lp_pack with ctl != NULL derives g_local
+ * from ctl[LADE_CTL_G] and (lp_rank, lp_world) on the device (graph replay; pass g_local = the padded row count's candidates). */
 int lade_lp_pack(const int32_t* am_out, const int32_t* am_inp, int32_t n_inp, const int32_t* am_guess, int32_t g_local,
-                 int32_t gs, int32_t split, int32_t* rec, int32_t rec_words, void* stream);
+                 int32_t gs, int32_t split, int32_t* rec, int32_t rec_words, const int32_t* ctl, int32_t lp_rank, int32_t lp_world,
+                 void* stream);
 int lade_lp_reduce_apply(const int32_t* all_rec, int32_t R, int32_t rec_words, int32_t split, int32_t* ctl,
                          int32_t* window, int32_t wcap, int32_t* pool_tok, int32_t* pool_cnt, int32_t V, int32_t W,
                          int32_t N, int32_t G, int32_t phase, int32_t* guess_all, int32_t* scratch, int32_t* record,

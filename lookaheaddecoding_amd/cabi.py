@@ -56,7 +56,7 @@ SIGNATURES = {
     "lade_mask_render": [C.POINTER(MaskParams), _vp, _vp],
     "lade_rope_kv_append": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "lade_kv_commit": [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp],
-    "lade_build_inputs": [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
+    "lade_build_inputs": [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp],
     "lade_argmax_rows": [_vp, _i64, _i32, _i32, _i32, _vp, _vp],
     "lade_verify_greedy": [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp],
     "lade_pool_insert_window": [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _vp],
@@ -68,7 +68,7 @@ SIGNATURES = {
     "lade_window_roll": [_vp, _i32, _vp, _vp, _i32, _i32, _vp],
     "lade_greedy_post_step": [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp,
                               _i32, _vp, _vp, _vp, _vp],
-    "lade_lp_pack": [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp],
+    "lade_lp_pack": [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _vp],
     "lade_lp_reduce_apply": [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp],
     "lade_lp_unique_id": [_vp],
     "lade_lp_comm_create": [_vp, _i32, _i32, C.POINTER(_vp)],

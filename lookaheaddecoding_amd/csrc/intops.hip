@@ -217,8 +217,16 @@ __global__ __launch_bounds__(64) void window_roll_kernel(int32_t* window, int wc
 __global__ __launch_bounds__(256) void build_inputs_kernel(const int32_t* in_ids, const int32_t* in_pos, int n_input,
                                                            const int32_t* window, int wcap, const int32_t* ctl, int fill_level,
                                                            int c0, int c1, const int32_t* guess, int g, int gs, int cand_rows,
-                                                           int32_t* ids, int32_t* pos, int32_t* out_T) {
-    if (g < 0) g = ctl[LADE_CTL_G];
+                                                           int32_t* ids, int32_t* pos, int32_t* out_T, int lp_rank, int lp_world) {
+    if (g < 0) {
+        g = ctl[LADE_CTL_G];
+        if (lp_world > 1) {        // this rank's share of the candidates, decided on the device (lade/decoding.py:956-963): graph replay
+            const int cnt = (g + lp_world - 1) / lp_world;
+            const int glo = min(cnt * lp_rank, g), ghi = min(cnt * (lp_rank + 1), g);
+            guess += glo * gs;
+            g = ghi - glo;
+        }
+    }
     // inputs default to the control block: the accepted tokens of the last step (hits[0..n_input), or
     // lst_token alone) at positions ending in ctl[LST_POS]
     const int lst_id = in_pos ? in_pos[n_input - 1] : ctl[LADE_CTL_LST_POS];
@@ -431,7 +439,13 @@ __global__ __launch_bounds__(64) void greedy_post_step_kernel(int32_t* ctl, int3
 // against `next_tokens` broadcast from rank 0 (:1024), so the verification runs on the gathered records, against
 // rank 0's first token, identically on every rank (16-bit logits may round differently from rank to rank).
 __global__ __launch_bounds__(64) void lp_pack_kernel(const int32_t* am_out, const int32_t* am_inp, int n_inp,
-                                                     const int32_t* am_guess, int g_local, int gs, int split, int32_t* rec) {
+                                                     const int32_t* am_guess, int g_local, int gs, int split, int32_t* rec,
+                                                     const int32_t* ctl, int lp_rank, int lp_world) {
+    if (ctl) {                     // graph replay: the rank's candidate count follows the device-side candidate count
+        const int g = ctl[LADE_CTL_G];
+        const int cnt = (g + lp_world - 1) / lp_world;
+        g_local = min(cnt * (lp_rank + 1), g) - min(cnt * lp_rank, g);
+    }
     if (threadIdx.x == 0) { rec[0] = *am_out; rec[1] = n_inp; rec[2] = g_local; rec[3] = 0; }
     for (int i = threadIdx.x; i < split; i += 64) rec[4 + i] = i < n_inp ? am_inp[i] : 0;
     for (int i = threadIdx.x; i < g_local * gs; i += 64) rec[4 + split + i] = am_guess[i];
@@ -596,13 +610,15 @@ extern "C" int lade_window_roll(int32_t* window, int32_t wcap, int32_t* ctl, con
 
 extern "C" int lade_build_inputs(const int32_t* in_ids, const int32_t* in_pos, int32_t n_input, const int32_t* window, int32_t wcap,
                                  const int32_t* ctl, int32_t fill_level, int32_t c0, int32_t c1, const int32_t* guess, int32_t g,
-                                 int32_t gs, int32_t cand_rows, int32_t* ids, int32_t* pos, int32_t* out_T, void* stream) {
+                                 int32_t gs, int32_t cand_rows, int32_t* ids, int32_t* pos, int32_t* out_T, int32_t lp_rank, int32_t lp_world,
+                                 void* stream) {
     LADE_REQUIRE(window && ctl && ids && pos && n_input > 0 && gs > 0 && fill_level >= 0 && fill_level < LADE_MAX_LEVEL,
                  LADE_E_ARG, "lade_build_inputs: n_input=%d gs=%d fill_level=%d", n_input, gs, fill_level);
+    LADE_REQUIRE(lp_world >= 1 && lp_rank >= 0 && lp_rank < lp_world, LADE_E_ARG, "lade_build_inputs: lp_rank=%d lp_world=%d", lp_rank, lp_world);
     LADE_REQUIRE(in_ids || n_input <= LADE_MAX_LEVEL, LADE_E_ARG, "lade_build_inputs: n_input=%d needs explicit in_ids", n_input);
     LADE_REQUIRE(guess || (g == 0 && cand_rows <= 0), LADE_E_ARG, "lade_build_inputs: candidates requested without a guess buffer");
     hipLaunchKernelGGL(build_inputs_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, in_ids, in_pos, n_input, window, wcap, ctl, fill_level,
-                       c0, c1, guess, g, gs, cand_rows, ids, pos, out_T);
+                       c0, c1, guess, g, gs, cand_rows, ids, pos, out_T, lp_rank, lp_world);
     return check_launch("lade_build_inputs");
 }
 
@@ -635,11 +651,14 @@ extern "C" int lade_greedy_post_step(int32_t* ctl, int32_t* window, int32_t wcap
 }
 
 extern "C" int lade_lp_pack(const int32_t* am_out, const int32_t* am_inp, int32_t n_inp, const int32_t* am_guess, int32_t g_local,
-                            int32_t gs, int32_t split, int32_t* rec, int32_t rec_words, void* stream) {
+                            int32_t gs, int32_t split, int32_t* rec, int32_t rec_words, const int32_t* ctl, int32_t lp_rank, int32_t lp_world,
+                            void* stream) {
+    LADE_REQUIRE(lp_world >= 1 && lp_rank >= 0 && lp_rank < lp_world, LADE_E_ARG, "lade_lp_pack: lp_rank=%d lp_world=%d", lp_rank, lp_world);
     LADE_REQUIRE(am_out && am_inp && rec && n_inp >= 0 && n_inp <= split && gs > 0 && gs < LADE_MAX_LEVEL &&
                      g_local >= 0 && g_local <= LADE_MAX_GUESS_SET && rec_words >= 4 + split + g_local * gs && (g_local == 0 || am_guess),
                  LADE_E_ARG, "lade_lp_pack: n_inp=%d split=%d gs=%d rec_words=%d g=%d", n_inp, split, gs, rec_words, g_local);
-    hipLaunchKernelGGL(lp_pack_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, am_out, am_inp, n_inp, am_guess, g_local, gs, split, rec);
+    hipLaunchKernelGGL(lp_pack_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, am_out, am_inp, n_inp, am_guess, g_local, gs, split, rec, ctl,
+                       lp_rank, lp_world);
     return check_launch("lade_lp_pack");
 }
 

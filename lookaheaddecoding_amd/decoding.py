@@ -172,7 +172,7 @@ class LookaheadDecoder:
         mask = StepMask.from_levels(1, self._level_sizes(N - 2), cand_rows, gs, 0)
         T = mask.T
         call("lade_build_inputs", None, None, 1, ptr(st.window), st.wcap, ptr(st.ctl), N - 2, 0, -1, ptr(st.guess), -1, gs, cand_rows,
-             ptr(st.ids), ptr(st.pos), None)
+             ptr(st.ids), ptr(st.pos), None, 0, 1)
         logits = e.forward(st.ids, st.pos, mask, self._graph_sel[gcap], 1 + W + cand_rows, dyn_P=st.ctl, n_splits=self._graph_splits[gcap])
         ops.argmax_rows(logits, out=st.am)
         if forward_only:
@@ -265,7 +265,7 @@ class LookaheadDecoder:
             mask = StepMask.from_levels(n_input, ls, cand_rows, gs, P)
             T, P_before = mask.T, P
             call("lade_build_inputs", None, None, n_input, ptr(st.window), st.wcap, ptr(st.ctl), min(fill_level, N - 2), 0, -1,
-                 ptr(st.guess), g if phase == 2 else 0, gs, cand_rows, ptr(st.ids), ptr(st.pos), None)
+                 ptr(st.guess), g if phase == 2 else 0, gs, cand_rows, ptr(st.ids), ptr(st.pos), None, 0, 1)
             n_inp = ls[-1]
             # rows whose logits are needed: out row, last level's rows, candidate rows (:1578-1606)
             rows = [n_input - 1] + list(range(T - cand_rows - n_inp, T - cand_rows)) + list(range(T - cand_rows, T))
@@ -421,7 +421,7 @@ class LookaheadDecoder:
             mask = StepMask.from_levels(1, ls, cand_rows, gs, P)
             T = mask.T
             call("lade_build_inputs", None, None, 1, ptr(st.window), st.wcap, ptr(st.ctl), min(fill_level, N - 2), 0, -1,
-                 ptr(st.guess), g if phase == 2 else 0, gs, cand_rows, ptr(st.ids), ptr(st.pos), None)
+                 ptr(st.guess), g if phase == 2 else 0, gs, cand_rows, ptr(st.ids), ptr(st.pos), None, 0, 1)
             n_inp = ls[-1]
             n_sel = self._set_sel([0] + list(range(T - cand_rows - n_inp, T - cand_rows)) + list(range(T - cand_rows, T)))
             logits = e.forward(st.ids, st.pos, mask, st.sel, n_sel).float()    # logits.float(), modeling_llama.py:1544

@@ -145,15 +145,81 @@ class HipLPBackend:
             T = mask.T
             guess_ptr = st.guess.data_ptr() + 4 * glo * gs
             call("lade_build_inputs", None, None, n_input, ptr(st.window), st.wcap, ptr(st.ctl), len(level_lens) - 1, c0, c1,
-                 guess_ptr, g_local if phase == 2 else 0, gs, cand_rows, ptr(st.ids), ptr(st.pos), None)
+                 guess_ptr, g_local if phase == 2 else 0, gs, cand_rows, ptr(st.ids), ptr(st.pos), None, 0, 1)
             n_inp = ls[-1]
             rows = [n_input - 1] + list(range(T - cand_rows - n_inp, T - cand_rows)) + list(range(T - cand_rows, T))
             d._set_sel(rows)                 # cached on the device per shape: no host-to-device copy in a steady step
             logits = e.forward(st.ids, st.pos, mask, st.sel, len(rows))
         self.ops.argmax_rows(logits, out=st.am)
         am = st.am.data_ptr()
-        call("lade_lp_pack", am, am + 4, n_inp, am + 4 * (1 + n_inp), g_local if phase == 2 else 0, gs, st.wcap, ptr(self.rec), self.rw)
+        call("lade_lp_pack", am, am + 4, n_inp, am + 4 * (1 + n_inp), g_local if phase == 2 else 0, gs, st.wcap, ptr(self.rec), self.rw, None, 0, 1)
         return self.rec
+
+    # ---- steady step as a hipGraph segment: [input assembly -> forward -> argmax -> record] ---------------------------------------
+    # Fixed shapes per (re-fed input count, candidate bucket): the rank's candidate share is decided on the device from ctl[G]
+    # (lade_build_inputs / lade_lp_pack with lp_rank, lp_world), unused candidate slots are padded, the cache length is read by the
+    # kernels from ctl[0].  The collective and lade_lp_reduce_apply follow on the same stream; the host only picks the segment and
+    # reads the step's record.
+    _capture_lock = __import__("threading").Lock()
+
+    def _local_buckets(self) -> List[int]:
+        gl = (self.dec.G + self.dec.lp.R - 1) // self.dec.lp.R
+        return sorted({0, (gl + 1) // 2, gl})
+
+    def _segment_body(self, n_input: int, ls: Sequence[int], c0: int, c1: int, gcap: int, sel: torch.Tensor, n_splits: int):
+        from .ops import StepMask
+        d, st, e = self.dec, self.dec.st, self.dec.e
+        gs, lp = d.gs, d.lp
+        call, ptr = self.call, self.ptr
+        cand_rows = gcap * gs
+        mask = StepMask.from_levels(n_input, ls, cand_rows, gs, 0)
+        call("lade_build_inputs", None, None, n_input, ptr(st.window), st.wcap, ptr(st.ctl), d.N - 2, c0, c1, ptr(st.guess), -1, gs, cand_rows,
+             ptr(st.ids), ptr(st.pos), None, lp.rank, lp.R)
+        logits = e.forward(st.ids, st.pos, mask, sel, sel.numel(), dyn_P=st.ctl, n_splits=n_splits)
+        self.ops.argmax_rows(logits, out=st.am)
+        am = st.am.data_ptr()
+        n_inp = ls[-1]
+        call("lade_lp_pack", am, am + 4, n_inp, am + 4 * (1 + n_inp), gcap, gs, st.wcap, ptr(self.rec), self.rw, ptr(st.ctl), lp.rank, lp.R)
+
+    def local_step_graph(self, P: int, n_input: int, level_lens: Sequence[int], c0: int, c1: int, g_local: int):
+        """Replays (capturing on first use) the segment for this step's shape; returns the record tensor."""
+        d, st, e = self.dec, self.dec.st, self.dec.e
+        gs = d.gs
+        ls = shard_level_sizes(level_lens, c0, c1)
+        gcap = min(b for b in self._local_buckets() if b >= g_local)
+        T = n_input + sum(ls) + gcap * gs
+        if P + T > e.S_max:
+            raise self.dec_error(f"KV cache exhausted: P={P} + T={T} > S_max={e.S_max}")
+        key = (n_input, gcap, e.generation)
+        graphs = self.__dict__.setdefault("_segments", {})
+        want_splits = e.n_splits_for(T, P + T)
+        ent = graphs.get(key)
+        if ent is None or abs(want_splits - ent[2]) >= 2:
+            rows = [n_input - 1] + list(range(T - gcap * gs - ls[-1], T))
+            sel = torch.tensor(rows, dtype=torch.int32, device=self.device)
+            n_splits = e.n_splits_for(T, max(P + T, 1024))
+            state = (st.ctl, st.window, st.pool_cnt, st.pool_tok, st.guess, st.tail)
+            with HipLPBackend._capture_lock:           # one capture at a time per process (ranks may be threads in the tests)
+                saved = [t.clone() for t in state]
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    self._segment_body(n_input, ls, c0, c1, gcap, sel, n_splits)       # warm-up: library handles, autotune
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                for t, sv in zip(state, saved):
+                    t.copy_(sv)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self._segment_body(n_input, ls, c0, c1, gcap, sel, n_splits)
+            ent = graphs[key] = (g, sel, n_splits)
+        ent[0].replay()
+        return self.rec
+
+    @staticmethod
+    def dec_error(msg):
+        from .cabi import LadeHipError
+        return LadeHipError(msg)
 
     def apply(self, all_rec: torch.Tensor, R: int, phase: int) -> List[int]:
         d, st = self.dec, self.dec.st
@@ -245,7 +311,10 @@ class LPRunner:
             level_lens = [W + N - 3 - fill_level] + [W + N - 2 - fill_level] * fill_level
         c0, c1 = window_shard(level_lens[0] + 1, R, r)
         glo, ghi = guess_shard(self.g, R, r) if phase == 2 else (0, 0)
-        rec = self.be.local_step(phase, self.P, self.n_input, level_lens, c0, c1, self.g, glo, ghi)
+        if phase == 2 and getattr(self.dec, "use_graph", False) and hasattr(self.be, "local_step_graph"):
+            rec = self.be.local_step_graph(self.P, self.n_input, level_lens, c0, c1, ghi - glo)
+        else:
+            rec = self.be.local_step(phase, self.P, self.n_input, level_lens, c0, c1, self.g, glo, ghi)
         self.all_gather(self.all_rec, rec)                                       # the ONE exchange of the step
         out = self.be.apply(self.all_rec, R, phase)
         self.steps += 1

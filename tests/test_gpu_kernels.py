@@ -433,7 +433,7 @@ def test_window_fill_roll_and_build_inputs_vs_oracle(lib):
             guess = None
             lay = O.build_step_layout([77], [41], past, None, fill_level, gs)
             ids = torch.zeros(256, dtype=torch.int32, device="cuda"); pos = torch.zeros(256, dtype=torch.int32, device="cuda"); oT = torch.zeros(1, dtype=torch.int32, device="cuda")
-            call("lade_build_inputs", None, None, 1, ptr(window), wcap, ptr(ctl), fill_level, 0, -1, None, 0, gs, -1, ptr(ids), ptr(pos), ptr(oT))
+            call("lade_build_inputs", None, None, 1, ptr(window), wcap, ptr(ctl), fill_level, 0, -1, None, 0, gs, -1, ptr(ids), ptr(pos), ptr(oT), 0, 1)
             assert oT.item() == lay.T and ids[:lay.T].cpu().tolist() == lay.ids and pos[:lay.T].cpu().tolist() == lay.positions
             O.window_fill(past, fill_level, inp)
             call("lade_window_fill", ptr(window), wcap, ptr(ctl), fill_level, ptr(dev(inp)), len(inp))
@@ -444,14 +444,14 @@ def test_window_fill_roll_and_build_inputs_vs_oracle(lib):
             guess = [rs.randrange(100) for _ in range(g * gs)]
             lay = O.build_step_layout([77], [41], past, guess if g else None, N - 2, gs)
             ids = torch.zeros(512, dtype=torch.int32, device="cuda"); pos = torch.zeros(512, dtype=torch.int32, device="cuda"); oT = torch.zeros(1, dtype=torch.int32, device="cuda")
-            call("lade_build_inputs", None, None, 1, ptr(window), wcap, ptr(ctl), N - 2, 0, -1, ptr(dev(guess + [0])), g, gs, -1, ptr(ids), ptr(pos), ptr(oT))
+            call("lade_build_inputs", None, None, 1, ptr(window), wcap, ptr(ctl), N - 2, 0, -1, ptr(dev(guess + [0])), g, gs, -1, ptr(ids), ptr(pos), ptr(oT), 0, 1)
             assert oT.item() == lay.T and ids[:lay.T].cpu().tolist() == lay.ids and pos[:lay.T].cpu().tolist() == lay.positions
             # lookahead-parallel shards of the same window
             for R in (2, 3):
                 for r in range(R):
                     pt, ws, we = O.lp_window_shard(past, R, r)
                     lay = O.build_step_layout([77], [41], pt, None, N - 2, gs)
-                    call("lade_build_inputs", None, None, 1, ptr(window), wcap, ptr(ctl), N - 2, ws, we, None, 0, gs, -1, ptr(ids), ptr(pos), ptr(oT))
+                    call("lade_build_inputs", None, None, 1, ptr(window), wcap, ptr(ctl), N - 2, ws, we, None, 0, gs, -1, ptr(ids), ptr(pos), ptr(oT), 0, 1)
                     assert oT.item() == lay.T and ids[:lay.T].cpu().tolist() == lay.ids and pos[:lay.T].cpu().tolist() == lay.positions, (W, N, R, r)
             new = [rs.randrange(100) for _ in range(W)]
             O.window_roll(past, new, N)

@@ -162,3 +162,64 @@ def test_lp_collective_through_the_c_abi_single_rank():
     finally:
         os.environ.pop("LADE_LP_COLLECTIVE", None)
     assert out.tokens == run["tokens"] and out.steps == run["steps"]
+
+
+def _lp_graph_threads(run, R):
+    from lookaheaddecoding_amd import parallel
+    from lookaheaddecoding_amd.decoding import LookaheadDecoder
+    from lookaheaddecoding_amd.engine import StepEngine
+    torch.zeros(1, device="cuda")
+    ex = ThreadExchange(R)
+    results, errors = {}, []
+
+    def rank_main(rank):
+        try:
+            torch.cuda.set_device(0)
+            cfg = make_config(run["model"], max_pos=512)
+            w = {k: torch.as_tensor(v) for k, v in random_weights_numpy(cfg, seed=run["model_seed"], std=run["std"]).items()}
+            eng = StepEngine(cfg, w, dtype=torch.float32, max_seq=512, max_T=320)
+            dec = LookaheadDecoder(eng, run["W"], run["N"], run["G"], lp=parallel.LPContext(rank=rank, world=R),
+                                   pool_from_prompt=bool(run.get("pool_from_prompt", 0)), use_graph=True)
+            be = parallel.HipLPBackend(dec)
+            be.broadcast_window = lambda w0, lp: (lambda t: (ex.broadcast(rank, t), t.tolist())[1])(torch.tensor(w0, dtype=torch.int32, device="cuda"))
+            with torch.cuda.stream(torch.cuda.Stream()):
+                out = parallel.greedy_lp(dec, run["prompt"], run["max_length"], eos_token_id=run.get("eos"), rng=random.Random(run["seed"] + 1000 * rank),
+                                         backend=be, all_gather=lambda o, i: ex.all_gather(rank, o, i))
+            results[rank] = (out.tokens, out.steps, len(getattr(be, "_segments", {})))
+        except Exception:  # pragma: no cover
+            import traceback
+            errors.append((rank, traceback.format_exc()))
+            try:
+                ex.bar.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(R)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors[0][1]
+    return results
+
+
+@pytest.mark.parametrize("idx", [0, 2, 5])
+def test_lp_steady_steps_as_graph_segments_match_reference_gloo_runs(idx):
+    """use_graph under lookahead parallelism: the rank-local part of a steady step (sharded input assembly with the candidate share
+    decided on the device, forward, argmax, record) replays as a hipGraph segment per (re-fed inputs, candidate bucket); tokens and
+    step counts of the reference's gloo runs, including runs whose hits are re-fed (n_input > 1) and POOL_FROM_PROMPT."""
+    with open(os.path.join(GOLDEN, "e2e_lp.json")) as f:
+        run = json.load(f)["runs"][idx]
+    res = _lp_graph_threads(run, run["R"])
+    for rank in range(run["R"]):
+        toks, steps, n_seg = res[rank]
+        assert toks == run["tokens"] and steps == run["steps"], (rank, idx)
+        assert n_seg >= 1, "no graph segment was captured"
+
+
+def test_lp_graph_segments_single_rank_equals_single_gpu_runs():
+    with open(os.path.join(GOLDEN, "e2e_greedy.json")) as f:
+        runs = json.load(f)["runs"]
+    for run in runs[:4]:
+        res = _lp_graph_threads(run, 1)
+        assert res[0][0] == run["tokens"] and res[0][1] == run["steps"]
