@@ -236,7 +236,15 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
     lade_mask_params m = a.m;
     if (a.dyn_P) m.P = *a.dyn_P;
     const int S_tot = m.P + m.T;
-    const int n_tiles = (S_tot + KT - 1) / KT;
+    int n_tiles = (S_tot + KT - 1) / KT;
+    if (m.is_prefill) {
+        // plain causal rows (prefill chunks, modeling_llama.py:124-130): no row of this block sees a key beyond its last token, so
+        // the tiles behind it are neither requested nor computed - the splits of the block partition only what it can see
+        const int r0 = blockIdx.x * ROWS, r1 = min(r0 + ROWS, n_rep * m.T) - 1;
+        const int hg0 = r0 / m.T, hg1 = r1 / m.T;
+        const int tmax = hg0 != hg1 ? m.T - 1 : r1 - hg1 * m.T;
+        n_tiles = min(n_tiles, (m.P + tmax + 1 + KT - 1) / KT);
+    }
     int base, stride, my_tiles;
     if (a.dbg & 64) {                               // interleaved: splits differ by at most one tile
         base = sp; stride = ns;
