@@ -100,7 +100,8 @@ def get_engine(model, need_seq: int, need_T: int, keep_rows: int = 0) -> StepEng
     # sized for the model's whole context window when that is affordable (<= 8 GiB of K/V), otherwise for what this call needs
     kv_bytes_per_row = 2 * cfg["layers"] * cfg["kv_heads"] * cfg["head_dim"] * model.lm_head.weight.element_size()
     full = cfg["max_pos"] if cfg["max_pos"] * kv_bytes_per_row <= (8 << 30) else 0
-    eng = StepEngine(cfg, weights_from_hf(model), dtype=dtype, device=dev, max_seq=max(need_seq, 2048, full), max_T=max(need_T, 512))
+    # step width 2048: long prompts prefill in few, wide causal chunks (the library GEMMs run ~30 % faster at 2048 rows than at 512)
+    eng = StepEngine(cfg, weights_from_hf(model), dtype=dtype, device=dev, max_seq=max(need_seq, 2048, full), max_T=max(need_T, 2048))
     setattr(model, _ENGINE_ATTR, eng)
     return eng
 
