@@ -176,6 +176,27 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
             if (m0 + row < g.M && n0 + c * 8 < g.N)
                 *reinterpret_cast<u32x4*>(g.C + (size_t)(m0 + row) * g.ldc + n0 + c * 8) = *reinterpret_cast<const u32x4*>(stg + row * RS + c * 16);
         }
+    } else if (g.dbg & 32) {
+        // experiment (LADE_GEMM_DBG=32): fp32 partials straight from the accumulators - lane (m = ql, hi) of tile (a, j) holds the four
+        // consecutive weight rows n = 8*g4 + 4*hi .. +3 of activation row m, one 16-byte store each, no LDS staging and no barrier in
+        // the tail.  Measured the same or slower than the staged whole-row stores below (7B, 60 rows: 92.9 vs 90.4-92.2 us per layer;
+        // gate/up 40.2 vs 37.5-39.2): what the partial stores cost (16 us per layer, tools/gemm_flags.py with LADE_GEMM_DBG=1) is
+        // their 48.6 MB, not the staging round trip.
+        float* outp = g.Cpart + (size_t)split * g.M * g.N;
+        if (computes)
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            const int m = m0 + (mw * MT + a) * 32 + ql;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int nb = n0 + (ng * NT + j) * 32 + 4 * hi;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+                    if (m < g.M && nb + 8 * g4 < g.N)
+                        *reinterpret_cast<float4*>(outp + (size_t)m * g.N + nb + 8 * g4) =
+                            float4{acc[a][j][4 * g4 + 0], acc[a][j][4 * g4 + 1], acc[a][j][4 * g4 + 2], acc[a][j][4 * g4 + 3]};
+            }
+        }
     } else {
         // fp32 partials [split][M][N]; stage through LDS in two halves of BN to stay within the ring
         constexpr int RSF = BN * 4 + 16;

@@ -34,6 +34,8 @@ def timeit(fn, reps=40, rounds=5):
     return best
 
 
+if os.environ.get("SHAPES") == "13b":      # CodeLlama-13B projections at the configurations the autotune picks for 120-row steps
+    CFG = {"qkv": (15360, 5120, 4, 4, 256, 0, 4), "o": (5120, 5120, 4, 2, 128, 0, 6), "gate_up": (27648, 5120, 4, 4, 256, 0, 2), "down": (5120, 13824, 4, 1, 192, 0, 9)}
 tot = 0.0
 line = []
 for name, (N, K, mb, mt, bn, nt, S) in CFG.items():
