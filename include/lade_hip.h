@@ -280,8 +280,11 @@ int lade_rmsnorm(const void* x, const void* weight, void* y, int32_t rows, int32
 /* y = x + r (residual add) fused with the norm of the sum: x <- x + r ; y = rmsnorm(x) */
 int lade_add_rmsnorm(void* x, const void* r, const void* weight, void* y, int32_t rows, int32_t hidden, float eps,
                      int32_t dtype, void* stream);
-/* out[r][i] = silu(gu[r][i]) * gu[r][inter + i]   (gate and up projections fused in one GEMM) */
-int lade_silu_mul(const void* gu, void* out, int32_t rows, int32_t inter, int32_t dtype, void* stream);
+/* SwiGLU of LlamaMLP (lade/models/modeling_llama.py:360-380) on the output of the fused gate/up GEMM, rounded like the separate torch ops.
+ * layout 0: gu rows are [gate (inter) | up (inter)]: out[r][i] = silu(gu[r][i]) * gu[r][inter + i].
+ * layout 1: groups of 16 - [16 gate | their 16 up] per 32 columns: out[r][i] = silu(gu[r][32*(i/16) + i%16]) * gu[r][32*(i/16) + 16 + i%16]
+ *           (the row order in which the step engine fuses the two weights, so that lade_gemm_skinny's SwiGLU epilogue is lane-local). */
+int lade_silu_mul(const void* gu, void* out, int32_t rows, int32_t inter, int32_t layout, int32_t dtype, void* stream);
 /* dst[r][:] = src[idx[r]][:]  (row gather: embedding lookup, logits-row selection) */
 int lade_gather_rows(const void* src, const int32_t* idx, void* dst, int32_t rows, int32_t width, int32_t elem_bytes,
                      int32_t src_rows, void* stream);
@@ -292,16 +295,19 @@ int lade_gather_rows(const void* src, const int32_t* idx, void* dst, int32_t row
  * order - deterministic - by lade_splitk_reduce).  bn = weight rows per work-group (32..256), mb = 32-row activation
  * blocks per work-group (1: 32 rows, 2: 64, 3: 96, 4: 128, 0: by M; larger M runs as several row blocks).  mt = 32-row activation blocks per WAVE (0 | 1..4, divides
  * mb) and nt = 32-row weight tiles per wave (0 = fewest): the waves form an (mb/mt) x (bn/32/nt) grid; larger wave tiles
- * re-read less from LDS per weight byte.  Unsupported shapes return LADE_E_ARG.  K % 64 == 0. */
+ * re-read less from LDS per weight byte.  Unsupported shapes return LADE_E_ARG.  K % 64 == 0.
+ * epilogue (n_split == 1 only): 0 = none; 1 = SwiGLU - W is the fused gate/up weight in the 16-row interleaved order of
+ * lade_silu_mul's layout 1 and C is [M][N/2] = silu(gate) * up (the SwiGLU kernel and the fp32 partials of a split-K
+ * gate/up GEMM disappear from the step). */
 int lade_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, float* Cpart,
                      int32_t M, int32_t N, int32_t K, int32_t n_split, int32_t bn, int32_t mb, int32_t mt, int32_t nt,
-                     int32_t dtype, void* stream);
+                     int32_t epilogue, int32_t dtype, void* stream);
 /* consumers that take a GEMM output as n_parts fp32 split-K partials [n_parts][rows][width] (part_stride elements
  * apart), sum them in split order and round once to the model dtype - so the split-K GEMM needs no reduce pass */
 int lade_add_rmsnorm_parts(void* x, const float* parts, int32_t n_parts, int64_t part_stride, const void* weight, void* y,
                            int32_t rows, int32_t hidden, float eps, int32_t dtype, void* stream);
 int lade_silu_mul_parts(const float* parts, int32_t n_parts, int64_t part_stride, void* out, int32_t rows, int32_t inter,
-                        int32_t dtype, void* stream);
+                        int32_t layout, int32_t dtype, void* stream);
 int lade_rope_kv_append_parts(const float* parts, int32_t n_parts, int64_t part_stride, void* q_out, const int32_t* positions,
                               const void* cos_tab, const void* sin_tab, void* k_cache, void* vt_cache, int32_t T, int32_t P,
                               const int32_t* dyn_P, int32_t H, int32_t Hkv, int32_t d, int32_t S_max, int32_t max_pos,

@@ -49,7 +49,11 @@ struct GemmK {
     int64_t lda, ldw, ldc;
     int M, N, K, n_split;
     int dbg;               // ablation switches for tools/gemm_ablate.py (LADE_GEMM_DBG): 1 = no output stores, 4 = no LDS reads / MFMA
+    int epi;               // n_split == 1 only: 0 = C = A.W^T;  1 = SwiGLU over interleaved gate / up rows, C is [M][N/2]
 };
+
+// value after one rounding to the model dtype (the GEMM output, then every elementwise op, rounds like torch does)
+template <typename T> __device__ __forceinline__ float g_rnd(float f) { return to_f32<T>(from_f32<T>(f)); }
 
 // Work-group tile = BM activation rows x BN weight rows, BM = 32*MW*MT, BN = 32*NG*NT: the waves form an MW x NG grid
 // (MW*NG <= 8 waves compute, all 8 issue DMA; m-group = w % MW, n-group = w / MW) and one wave owns MT x NT MFMA tiles
@@ -152,7 +156,37 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     g_barrier();
     if ((g.dbg & 1) && acc[0][0][0] != 12345.678f) return;
-    if (g.n_split == 1) {
+    if (g.n_split == 1 && g.epi == 1) {
+        // SwiGLU in the epilogue (LlamaMLP, lade/models/modeling_llama.py:360-380: act_fn(gate_proj(x)) * up_proj(x)).  The fused
+        // gate/up weight is interleaved in groups of 16 rows ([16 gate rows | their 16 up rows] per 32-row MFMA tile), so a lane's
+        // accumulators e and e+8 are gate and up of the same output column: the product is lane-local.  Rounded as the separate ops
+        // round: GEMM outputs to the dtype, silu to the dtype, product to the dtype.  out[m][16*tile + (e&3) + 8*(e>>2) + 4*hi].
+        if (computes)
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            const int m = m0 + (mw * MT + a) * 32 + ql;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int nrow = n0 + (ng * NT + j) * 32;              // first fused row of this tile
+                if (m < g.M && nrow < g.N) {
+                    uint16_t* dst = g.C + (size_t)m * g.ldc + nrow / 2 + 4 * hi;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        float o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float gt = g_rnd<T>(acc[a][j][4 * h + e]), up = g_rnd<T>(acc[a][j][8 + 4 * h + e]);
+                            o[e] = g_rnd<T>(gt / (1.f + __expf(-gt))) * up;
+                        }
+                        u32x2 w;
+                        w[0] = pack2<T>(o[0], o[1]);
+                        w[1] = pack2<T>(o[2], o[3]);
+                        *reinterpret_cast<u32x2*>(dst + 8 * h) = w;
+                    }
+                }
+            }
+        }
+    } else if (g.n_split == 1) {
         // stage [BM][BN] in the model dtype, then whole-row 16-byte stores
         constexpr int RS = BN * 2 + 16;
         unsigned char* stg = smem;
@@ -272,11 +306,13 @@ using namespace lade;
 // as there are waves).  The waves form an (mb/mt) x (bn/32/nt) grid.  Only the shapes in the table below are built.
 extern "C" int lade_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, float* Cpart,
                                 int32_t M, int32_t N, int32_t K, int32_t n_split, int32_t bn, int32_t mb, int32_t mt, int32_t nt,
-                                int32_t dtype, void* stream) {
+                                int32_t epilogue, int32_t dtype, void* stream) {
+    LADE_REQUIRE(epilogue == 0 || (epilogue == 1 && n_split == 1 && N % 32 == 0 && C != nullptr), LADE_E_ARG,
+                 "lade_gemm_skinny: epilogue=%d needs n_split == 1, N %% 32 == 0 and an output matrix", epilogue);
     LADE_REQUIRE(A && W && M > 0 && N > 0 && K > 0 && n_split >= 1, LADE_E_ARG, "lade_gemm_skinny: M=%d N=%d K=%d split=%d", M, N, K, n_split);
     LADE_REQUIRE(K % G_BK == 0 && lda % 8 == 0 && ldw % 8 == 0 && N % 8 == 0, LADE_E_ARG,
                  "lade_gemm_skinny: K=%d must be a multiple of %d, strides / N multiples of 8", K, G_BK);
-    LADE_REQUIRE(n_split == 1 ? (C != nullptr && ldc % 8 == 0) : (Cpart != nullptr), LADE_E_ARG, "lade_gemm_skinny: missing output buffer");
+    LADE_REQUIRE(n_split == 1 ? (C != nullptr && ldc % (epilogue ? 4 : 8) == 0) : (Cpart != nullptr), LADE_E_ARG, "lade_gemm_skinny: missing output buffer");
     LADE_REQUIRE(dtype == LADE_BF16 || dtype == LADE_F16, LADE_E_DTYPE, "lade_gemm_skinny: dtype=%d", dtype);
     if (mb == 0) mb = M <= 32 ? 1 : (M <= 64 ? 2 : (M <= 96 ? 3 : (M <= 128 ? 4 : (M <= 192 ? 6 : 8))));
     if (mt == 0) mt = mb <= 4 ? 1 : mb / 2;
@@ -284,7 +320,7 @@ extern "C" int lade_gemm_skinny(const void* A, int64_t lda, const void* W, int64
     LADE_REQUIRE(mb >= 1 && mb <= 8 && mt >= 1 && mt <= 4 && mb % mt == 0, LADE_E_ARG, "lade_gemm_skinny: mb=%d mt=%d", mb, mt);
     if (mb > 4 && bn > 128) bn = 128;      // 192 / 256-row work-groups: the activation tile leaves room for <= 128 weight rows per stage
     const int mw = mb / mt;
-    const int tiles = bn <= 32 ? 1 : (bn <= 64 ? 2 : (bn <= 128 ? 4 : (bn <= 192 ? 6 : 8)));      // 32-row weight tiles per work-group
+    const int tiles = bn <= 32 ? 1 : (bn <= 64 ? 2 : (bn <= 96 ? 3 : (bn <= 128 ? 4 : (bn <= 192 ? 6 : 8))));      // 32-row weight tiles per work-group
     if (nt == 0) {                                     // default: as many n-groups as waves allow
         const int ng_max = 8 / mw;
         nt = 1;
@@ -296,16 +332,17 @@ extern "C" int lade_gemm_skinny(const void* A, int64_t lda, const void* W, int64
     g.A = (const uint16_t*)A; g.W = (const uint16_t*)W; g.C = (uint16_t*)C; g.Cpart = Cpart;
     g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.n_split = n_split;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("LADE_GEMM_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
+    g.epi = epilogue;
     hipStream_t st = (hipStream_t)stream;
 #define SHAPE(TT, MWv, MTv, NGv, NTv) if (mw == MWv && mt == MTv && ng == NGv && nt == NTv) return launch_gemm<TT, MWv, MTv, NGv, NTv>(g, st);
 #define GO(TT)                                                                                                               \
-    /* 32 rows */  SHAPE(TT,1,1,1,1) SHAPE(TT,1,1,2,1) SHAPE(TT,1,1,4,1) SHAPE(TT,1,1,8,1) SHAPE(TT,1,1,2,2) SHAPE(TT,1,1,4,2)  \
-    /* 64 rows */  SHAPE(TT,2,1,1,1) SHAPE(TT,2,1,2,1) SHAPE(TT,2,1,4,1) SHAPE(TT,2,1,3,2) SHAPE(TT,2,1,4,2)                    \
+    /* 32 rows */  SHAPE(TT,1,1,1,1) SHAPE(TT,1,1,2,1) SHAPE(TT,1,1,4,1) SHAPE(TT,1,1,8,1) SHAPE(TT,1,1,2,2) SHAPE(TT,1,1,4,2) SHAPE(TT,1,1,3,1)  \
+    /* 64 rows */  SHAPE(TT,2,1,1,1) SHAPE(TT,2,1,2,1) SHAPE(TT,2,1,4,1) SHAPE(TT,2,1,3,2) SHAPE(TT,2,1,4,2) SHAPE(TT,2,1,3,1) SHAPE(TT,1,2,3,1)  \
                    SHAPE(TT,1,2,2,1) SHAPE(TT,1,2,4,1) SHAPE(TT,1,2,6,1) SHAPE(TT,1,2,8,1) SHAPE(TT,1,2,2,2) SHAPE(TT,1,2,3,2)  \
                    SHAPE(TT,1,2,4,2) SHAPE(TT,1,2,2,3) SHAPE(TT,1,2,2,4)                                                       \
-    /* 96 rows */  SHAPE(TT,3,1,1,1) SHAPE(TT,3,1,2,1) SHAPE(TT,3,1,2,2) SHAPE(TT,3,1,2,3) SHAPE(TT,3,1,2,4)                    \
+    /* 96 rows */  SHAPE(TT,3,1,1,1) SHAPE(TT,3,1,2,1) SHAPE(TT,3,1,2,2) SHAPE(TT,3,1,2,3) SHAPE(TT,3,1,2,4) SHAPE(TT,1,3,3,1)  \
                    SHAPE(TT,1,3,4,1) SHAPE(TT,1,3,6,1) SHAPE(TT,1,3,8,1) SHAPE(TT,1,3,3,2) SHAPE(TT,1,3,4,2)                    \
-    /* 128 rows */ SHAPE(TT,4,1,1,1) SHAPE(TT,4,1,2,1) SHAPE(TT,4,1,2,2) SHAPE(TT,4,1,2,3) SHAPE(TT,4,1,2,4)                    \
+    /* 128 rows */ SHAPE(TT,4,1,1,1) SHAPE(TT,4,1,2,1) SHAPE(TT,4,1,2,2) SHAPE(TT,4,1,2,3) SHAPE(TT,4,1,2,4) SHAPE(TT,1,4,3,1) SHAPE(TT,2,2,3,1)  \
                    SHAPE(TT,2,2,2,1) SHAPE(TT,2,2,4,1) SHAPE(TT,2,2,3,2) SHAPE(TT,2,2,4,2) SHAPE(TT,2,2,2,2)                    \
                    SHAPE(TT,1,4,4,1) SHAPE(TT,1,4,6,1) SHAPE(TT,1,4,8,1) SHAPE(TT,1,4,3,2) SHAPE(TT,1,4,4,2) SHAPE(TT,1,4,2,2)                    \
     /* 192 rows */ SHAPE(TT,2,3,2,1) SHAPE(TT,2,3,4,1) SHAPE(TT,2,3,2,2) SHAPE(TT,3,2,2,1) SHAPE(TT,3,2,2,2)                                     \

@@ -163,20 +163,24 @@ __global__ __launch_bounds__(BT) void rmsnorm_kernel(typename St<T>::S* x, const
 }
 
 // out[r][i] = silu(gu[r][i]) * gu[r][inter+i], rounded like torch: act(gate) -> dtype, then * up -> dtype
+// layout 0: a row is [gate (inter) | up (inter)] (two projections concatenated); layout 1: groups of 16 - [16 gate | their 16 up] - the
+// row order of the engine's fused gate/up weight (see the SwiGLU epilogue of gemm.hip)
 template <typename T>
 __global__ __launch_bounds__(256) void silu_mul_kernel(const typename St<T>::S* gu, typename St<T>::S* out, int inter, const float* parts,
-                                                       int n_parts, size_t part_stride) {
+                                                       int n_parts, size_t part_stride, int layout) {
     constexpr int N = Vec<T>::N;
     const size_t rb = (size_t)blockIdx.y * 2 * inter;
     const int i = (blockIdx.x * blockDim.x + threadIdx.x) * N;
     if (i >= inter) return;
+    const size_t gi = layout ? (size_t)(i >> 4) * 32 + (i & 15) : (size_t)i;
+    const size_t ui = layout ? gi + 16 : (size_t)inter + i;
     float g[N], u[N], o[N];
     if (parts) {
-        load_parts<T, N>(parts, n_parts, part_stride, rb + i, g);
-        load_parts<T, N>(parts, n_parts, part_stride, rb + inter + i, u);
+        load_parts<T, N>(parts, n_parts, part_stride, rb + gi, g);
+        load_parts<T, N>(parts, n_parts, part_stride, rb + ui, u);
     } else {
-        unpack<T>(*reinterpret_cast<const u32x4*>(gu + rb + i), g);
-        unpack<T>(*reinterpret_cast<const u32x4*>(gu + rb + inter + i), u);
+        unpack<T>(*reinterpret_cast<const u32x4*>(gu + rb + gi), g);
+        unpack<T>(*reinterpret_cast<const u32x4*>(gu + rb + ui), u);
     }
 #pragma unroll
     for (int e = 0; e < N; ++e) o[e] = rnd_st<T>(g[e] / (1.f + __expf(-g[e]))) * u[e];
@@ -295,13 +299,13 @@ extern "C" int lade_add_rmsnorm(void* x, const void* r, const void* weight, void
     return launch_rmsnorm<true>(x, r, weight, y, rows, hidden, eps, dtype, st);
 }
 
-extern "C" int lade_silu_mul(const void* gu, void* out, int32_t rows, int32_t inter, int32_t dtype, void* stream) {
-    LADE_REQUIRE(gu && out && rows >= 0 && inter > 0, LADE_E_ARG, "lade_silu_mul: rows=%d inter=%d", rows, inter);
+extern "C" int lade_silu_mul(const void* gu, void* out, int32_t rows, int32_t inter, int32_t layout, int32_t dtype, void* stream) {
+    LADE_REQUIRE(gu && out && rows >= 0 && inter > 0 && (layout == 0 || (layout == 1 && inter % 16 == 0)), LADE_E_ARG, "lade_silu_mul: rows=%d inter=%d layout=%d", rows, inter, layout);
     if (rows == 0) return LADE_OK;
     hipStream_t st = (hipStream_t)stream;
     LADE_REQUIRE(inter % 8 == 0, LADE_E_ARG, "lade_silu_mul: inter=%d must be a multiple of 8", inter);
     const int per_thr = dtype == LADE_F32 ? 4 : 8;
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(silu_mul_kernel<TT>, dim3(cdiv(inter / per_thr, 256), rows), dim3(256), 0, st, (const St<TT>::S*)gu, (St<TT>::S*)out, inter, (const float*)nullptr, 0, (size_t)0));
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(silu_mul_kernel<TT>, dim3(cdiv(inter / per_thr, 256), rows), dim3(256), 0, st, (const St<TT>::S*)gu, (St<TT>::S*)out, inter, (const float*)nullptr, 0, (size_t)0, layout));
     return check_launch("lade_silu_mul");
 }
 
@@ -340,13 +344,14 @@ extern "C" int lade_add_rmsnorm_parts(void* x, const float* parts, int32_t n_par
     return launch_rmsnorm<true>(x, nullptr, weight, y, rows, hidden, eps, dtype, (hipStream_t)stream, parts, n_parts, (size_t)part_stride);
 }
 
-extern "C" int lade_silu_mul_parts(const float* parts, int32_t n_parts, int64_t part_stride, void* out, int32_t rows, int32_t inter, int32_t dtype,
-                                   void* stream) {
-    LADE_REQUIRE(parts && out && rows >= 0 && inter > 0 && inter % 8 == 0 && n_parts >= 1, LADE_E_ARG, "lade_silu_mul_parts: bad args");
+extern "C" int lade_silu_mul_parts(const float* parts, int32_t n_parts, int64_t part_stride, void* out, int32_t rows, int32_t inter, int32_t layout,
+                                   int32_t dtype, void* stream) {
+    LADE_REQUIRE(parts && out && rows >= 0 && inter > 0 && inter % 8 == 0 && n_parts >= 1 && (layout == 0 || (layout == 1 && inter % 16 == 0)), LADE_E_ARG,
+                 "lade_silu_mul_parts: bad args");
     LADE_REQUIRE(dtype != LADE_F32, LADE_E_DTYPE, "lade_silu_mul_parts: 16-bit dtypes only");
     if (rows == 0) return LADE_OK;
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(silu_mul_kernel<TT>, dim3(cdiv(inter / 8, 256), rows), dim3(256), 0, st, (const St<TT>::S*)nullptr, (St<TT>::S*)out, inter,
-                                             parts, n_parts, (size_t)part_stride));
+                                             parts, n_parts, (size_t)part_stride, layout));
     return check_launch("lade_silu_mul_parts");
 }

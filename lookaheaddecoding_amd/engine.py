@@ -123,7 +123,7 @@ class StepEngine:
                 ln1=W(p + "ln1").contiguous(), ln2=W(p + "ln2").contiguous(),
                 wqkv=torch.cat([W(p + "wq"), W(p + "wk"), W(p + "wv")], dim=0).contiguous(),
                 wo=W(p + "wo").contiguous(),
-                wgu=torch.cat([W(p + "wg"), W(p + "wu")], dim=0).contiguous(),
+                wgu=self._fuse_gate_up(W(p + "wg"), W(p + "wu")),
                 wd=W(p + "wd").contiguous()))
         self._alloc_cache(self.S_max)
         self.attn_events = None             # set to a list to collect (start, end, T, n_splits) hipEvent pairs per layer
@@ -138,6 +138,13 @@ class StepEngine:
             self.n_cu = torch.cuda.get_device_properties(self.device.index).multi_processor_count
         except AssertionError:      # device count not initialised on this thread yet
             self.n_cu = 256
+
+    def _fuse_gate_up(self, wg: torch.Tensor, wu: torch.Tensor) -> torch.Tensor:
+        """gate and up projections as ONE weight.  16-row interleaved ([16 gate rows | their 16 up rows] per 32-row MFMA tile) so that
+        the GEMM's SwiGLU epilogue is lane-local; every consumer of the fused output (lade_silu_mul*, layout 1) knows the order.
+        Shapes whose intermediate size is not a multiple of 16 keep the plain [gate | up] concatenation (layout 0)."""
+        self.gu_layout = 1 if wg.shape[0] % 16 == 0 else 0
+        return ops.interleave_gate_up(wg, wu) if self.gu_layout else torch.cat([wg, wu], dim=0).contiguous()
 
     def _alloc_cache(self, S_max: int, keep_rows: int = 0) -> None:
         """KV cache [L][2][Hkv*S_max*d] (K: [Hkv][S_max][d], V: [Hkv][d][S_max]), zero-initialised; RoPE tables for it.
@@ -270,12 +277,30 @@ class StepEngine:
                 best_t = min(best_t, e0.elapsed_time(e1) / reps)
             return best_t
 
-        t_lib = time_it(lambda i: torch.matmul(a, ws[i % len(ws)].t(), out=out)) + 0.003      # + the consumer's extra read
+        # what follows the GEMM inside the step: a split-K or library gate/up GEMM is followed by the SwiGLU kernel (~6 us with its
+        # launch boundary), the fused-epilogue variant (S = 1 below) is not
+        tail = 0.006 if name == "wgu" else 0.0
+        t_lib = time_it(lambda i: torch.matmul(a, ws[i % len(ws)].t(), out=out)) + 0.003 + tail      # + the consumer's extra read
         best, t_best = None, t_lib
         for (mb, bn, S, mt, nt) in cands:
-            t = time_it(lambda i: ops.gemm_parts(a, ws[i % len(ws)], self.ws_part, S, bn, mb, mt, nt))
+            t = time_it(lambda i: ops.gemm_parts(a, ws[i % len(ws)], self.ws_part, S, bn, mb, mt, nt)) + tail
             if t < t_best:
                 best, t_best = (mb, bn, S, mt, nt), t
+        if name == "wgu" and self.gu_layout == 1:
+            # no split-K: BN weight rows x the whole K per work-group, SwiGLU in the epilogue, output in the model dtype.  Needs
+            # N / BN work-groups to cover the CUs on their own: 96-row blocks at the 7B / 13B widths.
+            act = torch.empty(a.shape[0], N // 2, dtype=self.dtype, device=self.device)
+            mbs = {32: 1, 64: 2, 96: 3, 128: 4, 192: 6, 256: 8}[mclass]
+            for bn in (64, 96, 128):
+                for mt in sorted({1, 2 if mbs % 2 == 0 else 1, mbs if mbs <= 4 else mbs // 2}):
+                    if mbs % mt or (mbs // mt) * (bn // 32) > 8:
+                        continue
+                    try:
+                        t = time_it(lambda i: ops.gemm_swiglu(a, ws[i % len(ws)], act, bn, mbs, mt, 1))
+                    except cabi.LadeHipError:
+                        continue                      # wave grid not built for this row class
+                    if t < t_best:
+                        best, t_best = (mbs, bn, 1, mt, 1), t
         return best
 
     GEMM_NAMES = ("wqkv", "wo", "wgu", "wd")
@@ -349,12 +374,14 @@ class StepEngine:
             else:
                 torch.matmul(o, lw["wo"].t(), out=r)
                 ops.add_rmsnorm(x, r, lw["ln2"], self.eps, out=h)
-            if cfg_gu:
+            if cfg_gu and cfg_gu[2] == 1:                 # gate/up GEMM + SwiGLU in one launch
+                ops.gemm_swiglu(h, lw["wgu"], a, cfg_gu[1], cfg_gu[0], cfg_gu[3], cfg_gu[4])
+            elif cfg_gu:
                 ops.gemm_parts(h, lw["wgu"], part, cfg_gu[2], cfg_gu[1], cfg_gu[0], cfg_gu[3], cfg_gu[4])
-                ops.silu_mul_parts(part, cfg_gu[2], T, self.inter, out=a)
+                ops.silu_mul_parts(part, cfg_gu[2], T, self.inter, out=a, layout=self.gu_layout)
             else:
                 torch.matmul(h, lw["wgu"].t(), out=gu)
-                ops.silu_mul(gu, out=a)
+                ops.silu_mul(gu, out=a, layout=self.gu_layout)
             if cfg_d:
                 ops.gemm_parts(a, lw["wd"], part, cfg_d[2], cfg_d[1], cfg_d[0], cfg_d[3], cfg_d[4])
                 r_parts = cfg_d[2]

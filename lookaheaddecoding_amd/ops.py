@@ -187,13 +187,22 @@ def add_rmsnorm(x: torch.Tensor, r: torch.Tensor, w: torch.Tensor, eps: float, o
     return out
 
 
-def silu_mul(gu: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def silu_mul(gu: torch.Tensor, out: Optional[torch.Tensor] = None, layout: int = 0) -> torch.Tensor:
+    """layout 0: gu rows = [gate | up]; 1: 16-row interleaved groups (the engine's fused gate/up order, see interleave_gate_up)"""
     assert gu.is_contiguous() and gu.shape[1] % 2 == 0
     inter = gu.shape[1] // 2
     if out is None:
         out = torch.empty(gu.shape[0], inter, dtype=gu.dtype, device=gu.device)
-    call("lade_silu_mul", ptr(gu), ptr(out), gu.shape[0], inter, dtype_code(gu))
+    call("lade_silu_mul", ptr(gu), ptr(out), gu.shape[0], inter, layout, dtype_code(gu))
     return out
+
+
+def interleave_gate_up(wg: torch.Tensor, wu: torch.Tensor) -> torch.Tensor:
+    """[inter, hid] x 2 -> fused [2*inter, hid] in groups of 16 rows: rows 32p .. 32p+15 = gate[16p ..], rows 32p+16 .. 32p+31 =
+    up[16p ..].  In an MFMA 32x32 output tile a lane's accumulators e and e+8 are then gate and up of the same column."""
+    inter, hid = wg.shape
+    assert wu.shape == wg.shape and inter % 16 == 0
+    return torch.stack([wg.view(inter // 16, 16, hid), wu.view(inter // 16, 16, hid)], dim=1).reshape(2 * inter, hid).contiguous()
 
 
 def gather_rows(src: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = None, rows: Optional[int] = None) -> torch.Tensor:
@@ -234,9 +243,19 @@ def gemm_skinny(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = 
         out = torch.empty(M, N, dtype=a.dtype, device=a.device)
     if n_split > 1 and part is None:
         part = torch.empty(n_split, M, N, dtype=torch.float32, device=a.device)
-    call("lade_gemm_skinny", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(out), out.stride(0), ptr(part), M, N, K, n_split, bn, mb, mt, nt, dtype_code(a))
+    call("lade_gemm_skinny", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(out), out.stride(0), ptr(part), M, N, K, n_split, bn, mb, mt, nt, 0, dtype_code(a))
     if n_split > 1:
         call("lade_splitk_reduce", ptr(part), ptr(out), out.stride(0), M, N, n_split, dtype_code(a))
+    return out
+
+
+def gemm_swiglu(a: torch.Tensor, w_gu: torch.Tensor, out: torch.Tensor, bn: int, mb: int, mt: int = 0, nt: int = 0) -> torch.Tensor:
+    """out[M, inter] = silu(a @ gate^T) * (a @ up^T) in ONE launch: w_gu is the 16-row interleaved fused weight (interleave_gate_up);
+    no split-K, no fp32 partials, no SwiGLU kernel."""
+    M, K = a.shape
+    N = w_gu.shape[0]
+    assert out.shape == (M, N // 2) and out.stride(1) == 1
+    call("lade_gemm_skinny", ptr(a), a.stride(0), ptr(w_gu), w_gu.stride(0), ptr(out), out.stride(0), None, M, N, K, 1, bn, mb, mt, nt, 1, dtype_code(a))
     return out
 
 
@@ -245,7 +264,7 @@ def gemm_parts(a: torch.Tensor, w: torch.Tensor, part: torch.Tensor, n_split: in
     `*_parts` consumer kernel - no reduce pass."""
     M, K = a.shape
     N = w.shape[0]
-    call("lade_gemm_skinny", ptr(a), a.stride(0), ptr(w), w.stride(0), None, 0, ptr(part), M, N, K, n_split, bn, mb, mt, nt, dtype_code(a))
+    call("lade_gemm_skinny", ptr(a), a.stride(0), ptr(w), w.stride(0), None, 0, ptr(part), M, N, K, n_split, bn, mb, mt, nt, 0, dtype_code(a))
 
 
 def add_rmsnorm_parts(x: torch.Tensor, part: torch.Tensor, n_parts: int, w: torch.Tensor, eps: float, out: torch.Tensor) -> torch.Tensor:
@@ -254,8 +273,8 @@ def add_rmsnorm_parts(x: torch.Tensor, part: torch.Tensor, n_parts: int, w: torc
     return out
 
 
-def silu_mul_parts(part: torch.Tensor, n_parts: int, rows: int, inter: int, out: torch.Tensor) -> torch.Tensor:
-    call("lade_silu_mul_parts", ptr(part), n_parts, rows * 2 * inter, ptr(out), rows, inter, dtype_code(out))
+def silu_mul_parts(part: torch.Tensor, n_parts: int, rows: int, inter: int, out: torch.Tensor, layout: int = 0) -> torch.Tensor:
+    call("lade_silu_mul_parts", ptr(part), n_parts, rows * 2 * inter, ptr(out), rows, inter, layout, dtype_code(out))
     return out
 
 

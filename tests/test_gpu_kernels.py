@@ -502,3 +502,41 @@ def test_glue_kernels_vs_torch(lib):
         lg = torch.randn(4, 1000).to(dtype)
         pr = ops.softmax_rows(lg.cuda(), 0.8).cpu()
         assert torch.allclose(pr, torch.softmax(lg.float() / 0.8, dim=-1), atol=1e-6, rtol=1e-4)
+
+
+def test_gate_up_gemm_with_swiglu_epilogue_and_interleaved_layout():
+    """lade_gemm_skinny(epilogue = 1): silu(a.Wg^T) * (a.Wu^T) in one launch over the 16-row interleaved fused weight, bit-identical to
+    the two-kernel path (GEMM -> lade_silu_mul layout 1) and equal to torch's ops on the un-fused weights up to GEMM rounding; the
+    layout-1 SwiGLU kernels (plain and split-K partials) against layout 0 on the same values."""
+    from lookaheaddecoding_amd import ops
+    torch.manual_seed(5)
+    for (M, inter, K) in ((60, 11008, 4096), (16, 256, 128), (120, 1408, 512), (33, 176, 64)):
+        a = torch.randn(M, K, device="cuda").bfloat16()
+        wg = (torch.randn(inter, K, device="cuda") * 0.05).bfloat16()
+        wu = (torch.randn(inter, K, device="cuda") * 0.05).bfloat16()
+        w = ops.interleave_gate_up(wg, wu)
+        # reference with torch's rounding order: the two GEMM outputs in bf16, silu in bf16, product in bf16
+        g, u = a @ wg.t(), a @ wu.t()
+        ref = torch.nn.functional.silu(g) * u
+        gu = a @ w.t()                                   # fused, interleaved columns
+        two_kernel = ops.silu_mul(gu.contiguous(), layout=1)
+        for (bn, mb, mt) in ((96, 0, 1), (64, 0, 1), (128, 0, 2), (96, 0, 2)):
+            out = torch.full((M, inter), float("nan"), dtype=torch.bfloat16, device="cuda")
+            mb = 1 if M <= 32 else 2 if M <= 64 else 3 if M <= 96 else 4
+            if mb % mt:
+                continue
+            try:
+                ops.gemm_swiglu(a, w, out, bn, mb, mt, 1)
+            except Exception as e:
+                if "no kernel" in str(e):                    # this wave grid is not built for the row class
+                    continue
+                raise
+            assert torch.isfinite(out.float()).all(), (M, inter, bn)
+            assert torch.allclose(out.float(), ref.float(), atol=3e-2, rtol=3e-2), (M, inter, bn, (out.float() - ref.float()).abs().max())
+        # layout 1 == layout 0 on the de-interleaved values, plain and from split-K partials
+        cat = torch.cat([g, u], dim=1).contiguous()
+        assert torch.equal(ops.silu_mul(cat, layout=0), ops.silu_mul(ops.interleave_gate_up(g.t().contiguous(), u.t().contiguous()).t().contiguous(), layout=1))
+        parts = torch.stack([gu.float() * 0.25, gu.float() * 0.75]).contiguous()
+        o1 = torch.empty(M, inter, dtype=torch.bfloat16, device="cuda")
+        ops.silu_mul_parts(parts, 2, M, inter, out=o1, layout=1)
+        assert torch.allclose(o1.float(), two_kernel.float(), atol=2e-2, rtol=2e-2)
