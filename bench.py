@@ -514,7 +514,8 @@ def _spawned(local_rank, n, port, argv):
 
 def main():
     args = parse()
-    if "WORLD_SIZE" in os.environ or args.gpus <= 1:       # launched by torch.distributed.run (one rank per process), or a single GPU
+    force_spawn = bool(int(os.environ.get("LADE_BENCH_FORCE_SPAWN", "0")))      # exercises the spawn path on a 1-GPU box (tests)
+    if "WORLD_SIZE" in os.environ or (args.gpus <= 1 and not force_spawn):       # launched by torch.distributed.run (one rank per process), or a single GPU
         os.environ.setdefault("WORLD_SIZE", "1")
         return worker(args)
     # `python bench.py --gpus N`: start the N ranks ourselves, one process per GPU, RCCL over xGMI between them

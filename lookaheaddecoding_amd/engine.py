@@ -247,10 +247,12 @@ class StepEngine:
         out = torch.empty(a.shape[0], N, dtype=self.dtype, device=self.device)
         cands = []
         # (m-blocks per work-group, m-blocks per wave, n-tiles per wave (0 = fewest), weight rows per work-group)
-        shapes = {32: ((1, 1, 0, (64, 128, 256)), (1, 1, 2, (128, 256)), (2, 1, 0, (128,))),
-                  64: ((2, 1, 0, (128, 256)), (2, 2, 0, (128, 192, 256)), (2, 2, 2, (192, 256))),
-                  96: ((3, 1, 0, (64, 128, 192, 256)), (3, 3, 0, (128, 192, 256)), (3, 3, 2, (192, 256)), (4, 1, 0, (128, 192)), (4, 2, 0, (128, 192))),
-                  128: ((4, 1, 0, (64, 128, 192, 256)), (4, 2, 0, (128, 192, 256)), (4, 4, 0, (192, 256)), (4, 4, 2, (192, 256))),
+        shapes = {32: ((1, 1, 0, (64, 128, 256)), (1, 1, 2, (128, 256)), (2, 1, 0, (128,)), (1, 1, 1, (96,))),
+                  64: ((2, 1, 0, (128, 256)), (2, 2, 0, (128, 192, 256)), (2, 2, 2, (192, 256)), (2, 1, 1, (64, 96)), (2, 2, 1, (96,))),
+                  96: ((3, 1, 0, (64, 128, 192, 256)), (3, 3, 0, (128, 192, 256)), (3, 3, 2, (192, 256)), (4, 1, 0, (128, 192)), (4, 2, 0, (128, 192)),
+                       (3, 3, 1, (96,))),
+                  128: ((4, 1, 0, (64, 128, 192, 256)), (4, 2, 0, (128, 192, 256)), (4, 4, 0, (192, 256)), (4, 4, 2, (192, 256)), (4, 4, 1, (96,)),
+                        (4, 2, 1, (96,))),
                   # 192 / 256 rows (config 4's 120 + 6g-token steps, hot-regime steps): the activation tile alone is 24 / 32 KB per stage,
                   # so the weight tile stays at <= 128 rows for the 3-stage ring to fit the 160 KB of LDS
                   192: ((6, 3, 1, (64, 128)), (6, 3, 2, (128,)), (6, 2, 1, (64,)), (6, 2, 2, (128,))),

@@ -46,3 +46,18 @@ def test_eval_harness_writes_answers_stats_and_log(tmp_path):
     log = torch.load(ans + "-lade-log.pt")
     assert len(log) == 6 and all(e[0] == 24 and e[1] <= 24 for e in log)          # [generated, steps, ratio] per generate call
     assert "AVERAGE THROUGHPUT1" in out and "LADE LOG - OVERALL GEN:  144" in out
+
+
+def test_bench_spawns_its_own_ranks_and_prints_one_json_line_last():
+    """`python bench.py --gpus N` without a launcher starts its ranks itself (torch.multiprocessing.spawn, one per GPU, RCCL between
+    them).  One GPU here: the spawn path is exercised with one rank on the lookahead-parallel code path (real RCCL group), a reduced
+    layer count, and the contract is checked on what it prints: the JSON line is the last line of stdout."""
+    out = _run(["bench.py", "--gpus", "1", "--force-lp", "--layers", "2", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--prompt-len", "256"],
+               {"LADE_BENCH_FORCE_SPAWN": "1"})
+    lines = [l for l in out.splitlines() if l.strip()]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["config"]["parallelism"] == "lp1" and d["value"] > 0
+    assert d["scaling"] == "weak" and d["roofline"]["bound"] == "hbm" and "prefill" in d
+    # asking for more GPUs than the box has fails loudly instead of silently running one rank
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "3", "--steps", "1"], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "GPU" in (r.stderr + r.stdout)
