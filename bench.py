@@ -94,7 +94,7 @@ def pmc_traffic(T, P, n_splits):
         try:
             with open(path) as f:
                 for e in json.load(f)["entries"]:
-                    if e["T"] == T and abs(e["P"] - P) <= 64 and e["n_splits"] == n_splits:
+                    if e["T"] == T and abs(e["P"] - P) <= 128 and e["n_splits"] == n_splits:      # 128 keys = 2 MB of 36: within the counters' spread
                         return e["traffic_bytes"], f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/attn_bench.py at this shape; not collected by this run)"
         except Exception:
             pass
