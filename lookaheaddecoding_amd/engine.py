@@ -281,11 +281,16 @@ class StepEngine:
 
         # what follows the GEMM inside the step: a split-K or library gate/up GEMM is followed by the SwiGLU kernel (~6 us with its
         # launch boundary), the fused-epilogue variant (S = 1 below) is not
-        tail = 0.006 if name == "wgu" else 0.0
-        t_lib = time_it(lambda i: torch.matmul(a, ws[i % len(ws)].t(), out=out)) + 0.003 + tail      # + the consumer's extra read
+        # (a dependent launch ~2.5 us + its reads of the GEMM output at ~4 TB/s: 6.3 us measured behind 4 partials of the 7B shape
+        # at 60 rows, ~9 us behind 2 partials of the 13B shape at 120 rows; times here are in ms)
+        Mrows = a.shape[0]
+        tail = (lambda out_bytes: 0.0025 + out_bytes / 4e9) if name == "wgu" else (lambda out_bytes: 0.0)
+        if name == "wgu" and os.environ.get("LADE_GU_TAIL_FIXED"):          # experiment: the flat 6 us estimate
+            tail = lambda out_bytes: 0.006
+        t_lib = time_it(lambda i: torch.matmul(a, ws[i % len(ws)].t(), out=out)) + 0.003 + tail(Mrows * N * 2)      # + the consumer's extra read
         best, t_best = None, t_lib
         for (mb, bn, S, mt, nt) in cands:
-            t = time_it(lambda i: ops.gemm_parts(a, ws[i % len(ws)], self.ws_part, S, bn, mb, mt, nt)) + tail
+            t = time_it(lambda i: ops.gemm_parts(a, ws[i % len(ws)], self.ws_part, S, bn, mb, mt, nt)) + tail(S * Mrows * N * 4)
             if t < t_best:
                 best, t_best = (mb, bn, S, mt, nt), t
         if name == "wgu" and self.gu_layout == 1:
