@@ -461,7 +461,7 @@ def worker(args):
                     "launch_us": round(us, 2), "launch_us_source": how, "algorithmic_bytes": alg, "T": T_k, "P": P_end,
                     "mfma": {"useful_flops": flops, "achieved_tflops": round(flops / (us * 1e-6) / 1e12, 1), "peak_tflops": 2500.0,
                              "frac": round(flops / (us * 1e-6) / 1e12 / 2500.0, 4),
-                             "note": "useful flops of the closed-form mask (SURVEY 8d) / the same launch time / dense bf16 MFMA peak; utilisation counters: profiles/r2_attn_mfma_*.csv"},
+                             "note": "useful flops of the closed-form mask (SURVEY 8d) / the same launch time / dense bf16 MFMA peak; utilisation counters: profiles/r2_pmc/A7_mfma.csv (T=60), A7B_mfma.csv (T=120), A70_mfma.csv (70B LP shard)"},
                     "launch_us_in_step": None if in_situ is None else {k: (round(v, 2) if isinstance(v, float) else v) for k, v in in_situ.items()},
                     "launch_us_graph_delta": None if graph_delta is None else {k: (round(v, 2) if isinstance(v, float) else v) for k, v in graph_delta.items()},
                     "launch_us_isolated": round(us_iso, 2),
