@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import math
 import os
+import sys
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -289,8 +290,11 @@ class StepEngine:
             tail = lambda out_bytes: 0.006
         t_lib = time_it(lambda i: torch.matmul(a, ws[i % len(ws)].t(), out=out)) + 0.003 + tail(Mrows * N * 2)      # + the consumer's extra read
         best, t_best = None, t_lib
+        log = [] if os.environ.get("LADE_TUNE_VERBOSE") else None        # tools/gemm_tune_probe.py: every candidate's time
         for (mb, bn, S, mt, nt) in cands:
             t = time_it(lambda i: ops.gemm_parts(a, ws[i % len(ws)], self.ws_part, S, bn, mb, mt, nt)) + tail(S * Mrows * N * 4)
+            if log is not None:
+                log.append((t, (mb, bn, S, mt, nt)))
             if t < t_best:
                 best, t_best = (mb, bn, S, mt, nt), t
         if name == "wgu" and self.gu_layout == 1:
@@ -306,8 +310,15 @@ class StepEngine:
                         t = time_it(lambda i: ops.gemm_swiglu(a, ws[i % len(ws)], act, bn, mbs, mt, 1))
                     except cabi.LadeHipError:
                         continue                      # wave grid not built for this row class
+                    if log is not None:
+                        log.append((t, (mbs, bn, 1, mt, 1)))
                     if t < t_best:
                         best, t_best = (mbs, bn, 1, mt, 1), t
+        if log is not None:
+            mbytes = N * K * ws[0].element_size() / 1e6
+            top = " ".join(f"{c}:{t * 1e3:.1f}" for t, c in sorted(log)[:5])
+            print(f"[tune] {name}:{mclass} rows={Mrows} N={N} K={K} lib {t_lib * 1e3:.1f} us | best {best} {t_best * 1e3:.1f} us "
+                  f"({mbytes / (t_best * 1e3):.2f} TB/s) | {top}", file=sys.stderr, flush=True)
         return best
 
     GEMM_NAMES = ("wqkv", "wo", "wgu", "wd")
