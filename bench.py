@@ -231,10 +231,16 @@ def worker(args):
         c["G"] = args.guess
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
-    if torch.cuda.device_count() <= local_rank:
-        raise SystemExit(f"rank {rank} needs cuda:{local_rank}, this box has {torch.cuda.device_count()} GPU(s)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # tests only (LADE_BENCH_SHARE_GPU=1): several ranks on ONE device, so that the N > 1 path of this file runs end to end on a 1-GPU
+    # box.  RCCL refuses two ranks per device, the collectives then go through gloo (LADE_BENCH_BACKEND=gloo); nothing is reported as a
+    # measurement from such a run ("shared_gpu" in the config).
+    share_gpu = os.environ.get("LADE_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("LADE_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if share_gpu else local_rank
+    if torch.cuda.device_count() <= dev_index:
+        raise SystemExit(f"rank {rank} needs cuda:{dev_index}, this box has {torch.cuda.device_count()} GPU(s)")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     use_lp = world > 1 or args.force_lp or bool(c.get("lp"))
     sampling = c["mode"] == "sample"
@@ -244,7 +250,7 @@ def worker(args):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
 
     from lookaheaddecoding_amd import ops
     from lookaheaddecoding_amd.decoding import LookaheadDecoder
@@ -485,7 +491,7 @@ def worker(args):
             "config": {"workload": f"{c['what']}; {c['model']}-shape ({cfg['layers']}L) {args.dtype} {mode} lookahead, 1 sequence, prompt {args.prompt_len}, "
                                    f"W={W} N={N} G={G}, cold regime (untied random weights)", "name": args.config,
                        "parallelism": f"lp{world}" if use_lp else "single", "tokens_per_step_T": round(avg_T, 1), "kv_len_end": P_end,
-                       "hipgraph": bool(dec.use_graph)},
+                       "hipgraph": bool(dec.use_graph), **({"shared_gpu": True, "backend": backend} if share_gpu else {})},
             "step_compression": round(S, 3), "steps_per_s": round(args.steps / elapsed, 2),
             "prefill": {"tokens": args.prompt_len + W + N - 3, "ms": round(prefill_s * 1e3, 2), "tokens_per_s": round((args.prompt_len + W + N - 3) / prefill_s, 1),
                         "how": f"prompt + first window level as causal chunks of <= {args.chunk} rows through the same attention / GEMM kernels, lm_head on the "
@@ -519,7 +525,7 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         return worker(args)
     # `python bench.py --gpus N`: start the N ranks ourselves, one process per GPU, RCCL over xGMI between them
-    if torch.cuda.device_count() < args.gpus:
+    if torch.cuda.device_count() < args.gpus and os.environ.get("LADE_BENCH_SHARE_GPU") != "1":
         raise SystemExit(f"--gpus {args.gpus}: this box has {torch.cuda.device_count()} GPU(s)")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

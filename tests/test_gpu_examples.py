@@ -61,3 +61,17 @@ def test_bench_spawns_its_own_ranks_and_prints_one_json_line_last():
     # asking for more GPUs than the box has fails loudly instead of silently running one rank
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "3", "--steps", "1"], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "GPU" in (r.stderr + r.stdout)
+
+
+def test_bench_two_ranks_end_to_end_on_one_gpu():
+    """The N > 1 path of bench.py from the first line to the JSON line: two spawned ranks, lookahead parallelism between them (window and
+    candidates sharded, one all-gather per step, GEMM choices of rank 0 adopted by rank 1, max-over-ranks timing).  Both ranks sit on the
+    one GPU of this box, which RCCL refuses, so the process group is gloo here (LADE_BENCH_SHARE_GPU / LADE_BENCH_BACKEND, test-only
+    switches); the token-level parity of the sharded step is pinned in test_gpu_lp.py / test_lp_gloo.py."""
+    out = _run(["bench.py", "--gpus", "2", "--layers", "2", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--prompt-len", "256"],
+               {"LADE_BENCH_SHARE_GPU": "1", "LADE_BENCH_BACKEND": "gloo"})
+    lines = [l for l in out.splitlines() if l.strip()]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["config"]["parallelism"] == "lp2" and d["config"]["shared_gpu"] is True
+    assert d["scaling"] == "strong" and d["value"] > 0 and d["step_compression"] >= 1.0
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["T"] < 60          # rank 0's shard of the 60-token step
