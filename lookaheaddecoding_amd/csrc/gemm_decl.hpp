@@ -1,0 +1,27 @@
+// Shared between the C entry points (gemm.hip) and the per-dtype translation units of the skinny GEMM (gemm_bf16.hip, gemm_f16.hip).
+#pragma once
+#include "common.hpp"
+
+namespace lade {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int G_BK = 64;          // K depth of one LDS tile (128-byte rows)
+
+struct GemmK {
+    const uint16_t* A;     // [M][lda]
+    const uint16_t* W;     // [N][ldw]
+    uint16_t* C;           // [M][ldc] model dtype (n_split == 1)
+    float* Cpart;          // [n_split][M][N] fp32 (n_split > 1)
+    int64_t lda, ldw, ldc;
+    int M, N, K, n_split;
+    int dbg;               // ablation switches for tools/gemm_ablate.py (LADE_GEMM_DBG): 1 = no output stores, 4 = no LDS reads / MFMA
+    int epi;               // n_split == 1 only: 0 = C = A.W^T;  1 = SwiGLU over interleaved gate / up rows, C is [M][N/2]
+};
+
+// launch the kernel built for this wave grid (mw x ng waves compute, mt x nt MFMA tiles each); -1 when it is not in the shape table
+int gemm_dispatch_bf16(const GemmK& g, hipStream_t st, int mw, int mt, int ng, int nt);
+int gemm_dispatch_f16(const GemmK& g, hipStream_t st, int mw, int mt, int ng, int nt);
+
+}  // namespace lade

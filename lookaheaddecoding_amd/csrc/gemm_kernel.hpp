@@ -1,0 +1,302 @@
+// Kernel template of the skinny weight-streaming GEMM and its shape table.  Included by gemm_bf16.hip / gemm_f16.hip (one translation
+// unit per dtype, so that the instantiations compile in parallel); gemm.hip holds the C entry points.
+#pragma once
+#include "common.hpp"
+#include "gemm_decl.hpp"
+
+namespace lade {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int G_NSTAGE = 3;       // LDS ring depth: two tiles stay in flight while one is multiplied
+constexpr int G_THREADS = 512;
+
+__device__ __forceinline__ void g_barrier() { asm volatile("s_barrier" ::: "memory"); }
+template <int N> __device__ __forceinline__ void g_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// 128-byte rows: two rows per 256-byte bank row, XOR the 16-byte chunk index with (row/2)&7
+__device__ __forceinline__ int g_off(int row, int c16) { return row * 128 + ((c16 ^ ((row >> 1) & 7)) << 4); }
+
+template <typename T> struct GMfma;
+template <> struct GMfma<BF16> {
+    __device__ static __forceinline__ f32x16 run(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct GMfma<F16> {
+    __device__ static __forceinline__ f32x16 run(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+
+
+// value after one rounding to the model dtype (the GEMM output, then every elementwise op, rounds like torch does)
+template <typename T> __device__ __forceinline__ float g_rnd(float f) { return to_f32<T>(from_f32<T>(f)); }
+
+// Work-group tile = BM activation rows x BN weight rows, BM = 32*MW*MT, BN = 32*NG*NT: the waves form an MW x NG grid
+// (MW*NG <= 8 waves compute, all 8 issue DMA; m-group = w % MW, n-group = w / MW) and one wave owns MT x NT MFMA tiles
+// of 32 x 32.  Per 16-deep K step a wave reads MT activation + NT weight fragments from LDS for MT*NT MFMAs, so the LDS
+// bytes read per weight byte are 8 waves * (MT + NT) / (NG*NT) ... = (MT + NT) / NT * MW (+ the DMA write): with MT = 1 a
+// 128-row step moves ~7 LDS bytes per weight byte and the 128 B/clk LDS port caps a CU at ~38 GB/s of weights; 2 x 2
+// wave tiles bring that to ~5.5.
+template <typename T, int MW, int MT, int NG, int NT>
+__global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
+    static_assert(MW * NG <= 8, "at most 8 computing waves");
+    constexpr int NW = G_THREADS / 64;          // all 8 waves move DMA pieces, the first MW * NG of them compute
+    constexpr int MB = MW * MT;
+    constexpr int BN = 32 * NT * NG;
+    constexpr int BM = 32 * MB;
+    // a stage = one 64-deep K tile: [weight tile | activation tile]
+    constexpr int W_BYTES = BN * 128, A_BYTES = BM * 128, STAGE = W_BYTES + A_BYTES;
+    constexpr int W_PIECES = W_BYTES / 1024, A_PIECES = A_BYTES / 1024;      // 1-KiB DMA pieces per tile
+    constexpr int TOTAL_PIECES = W_PIECES + A_PIECES;
+    constexpr int PIECES = (TOTAL_PIECES + NW - 1) / NW;                     // per wave and stage (the tail repeats the last piece)
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mw = wave % MW, ng = wave / MW;
+    const bool computes = ng < NG;
+    const int ql = lane & 31, hi = lane >> 5;
+    const int n0 = blockIdx.x * BN, split = blockIdx.y, m0 = blockIdx.z * BM;
+
+    const int k_tiles = (g.K + G_BK - 1) / G_BK;
+    const int tps = (k_tiles + g.n_split - 1) / g.n_split;
+    const int t0 = split * tps;
+    const int nt = max(0, min(t0 + tps, k_tiles) - t0);
+
+    // ---- this wave's DMA pieces, resolved ONCE: per piece a lane's source pointer at the split's first K tile and the piece's offset
+    // inside a stage.  Inside the K loop a piece then costs one 64-bit add, the M0 write
+    // and the global_load_lds.  (Left inside the loop, the address arithmetic - two clamps, a 64-bit multiply, and the kernel
+    // arguments re-read through the scalar cache after every asm barrier - cost a wave ~120 ns per piece: more than the transfer.)
+    const bool moves = wave * PIECES < TOTAL_PIECES;     // a wave moves PIECES pieces or none (vmcnt is per wave: nothing requested, nothing to wait for)
+    const uint16_t* p_src[PIECES];
+    int p_dst[PIECES];
+    bool p_w[PIECES];
+    const bool nt_weights = !(g.dbg & 16);
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+        const int piece = min(wave * PIECES + i, TOTAL_PIECES - 1);
+        const bool isw = piece < W_PIECES;
+        const int p = isw ? piece : piece - W_PIECES;
+        const int row = p * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        p_src[i] = (isw ? g.W + (size_t)min(n0 + row, g.N - 1) * g.ldw : g.A + (size_t)min(m0 + row, g.M - 1) * g.lda) + (size_t)t0 * G_BK + c * 8;
+        p_dst[i] = (isw ? 0 : W_BYTES) + p * 1024;
+        p_w[i] = isw;
+    }
+    // tile j of this split into ring slot `stage`
+    auto issue = [&](int j, int stage) {
+        if (!moves) return;
+        unsigned char* sbase = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const uint16_t* src = p_src[i] + j * G_BK;
+            unsigned char* dst = sbase + p_dst[i];
+            // the weight stream is non-temporal (aux = 2): every weight byte is read by exactly one work-group, once per step, so
+            // keeping it in L2 / the Infinity Cache only evicts what is re-read (activation tiles, partials).  Measured on the four
+            // 7B projections at 60 rows: 97.2 -> 92.0 us per layer, decode step 4.65 -> 4.51 ms (LADE_GEMM_DBG=16 turns it off)
+            if (p_w[i] && nt_weights)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 2);
+            else
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < G_NSTAGE; ++s)
+        if (s < nt) issue(s, s);
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][i][e] = 0.f;
+
+    for (int i = 0; i < nt; ++i) {
+        const int stage = i % G_NSTAGE;
+        const int younger = min(nt, i + G_NSTAGE) - (i + 1);        // tiles requested after tile i that may stay in flight
+        if (younger >= 2) g_wait_vm<2 * PIECES>();
+        else if (younger == 1) g_wait_vm<PIECES>();
+        else g_wait_vm<0>();
+        g_barrier();
+        const unsigned char* ws = smem + stage * STAGE;
+        const unsigned char* as = ws + W_BYTES;
+        if (computes && !(g.dbg & 4))
+#pragma unroll
+        for (int kk = 0; kk < G_BK / 16; ++kk) {
+            u32x4 af[MT], wf[NT];
+#pragma unroll
+            for (int a = 0; a < MT; ++a) af[a] = *reinterpret_cast<const u32x4*>(as + g_off((mw * MT + a) * 32 + ql, kk * 2 + hi));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const u32x4*>(ws + g_off((ng * NT + j) * 32 + ql, kk * 2 + hi));
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[a][j] = GMfma<T>::run(wf[j], af[a], acc[a][j]);
+        }
+        if (i + G_NSTAGE < nt) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            g_barrier();
+            issue(i + G_NSTAGE, stage);
+        }
+    }
+
+    // ---- epilogue: C^T tile (lane = activation row ql of block mb, 16 weight rows per MFMA tile) -> row-major C ----
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    g_barrier();
+    if ((g.dbg & 1) && acc[0][0][0] != 12345.678f) return;
+    if (g.n_split == 1 && g.epi == 1) {
+        // SwiGLU in the epilogue (LlamaMLP, lade/models/modeling_llama.py:360-380: act_fn(gate_proj(x)) * up_proj(x)).  The fused
+        // gate/up weight is interleaved in groups of 16 rows ([16 gate rows | their 16 up rows] per 32-row MFMA tile), so a lane's
+        // accumulators e and e+8 are gate and up of the same output column: the product is lane-local.  Rounded as the separate ops
+        // round: GEMM outputs to the dtype, silu to the dtype, product to the dtype.  out[m][16*tile + (e&3) + 8*(e>>2) + 4*hi].
+        if (computes)
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            const int m = m0 + (mw * MT + a) * 32 + ql;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int nrow = n0 + (ng * NT + j) * 32;              // first fused row of this tile
+                if (m < g.M && nrow < g.N) {
+                    uint16_t* dst = g.C + (size_t)m * g.ldc + nrow / 2 + 4 * hi;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        float o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float gt = g_rnd<T>(acc[a][j][4 * h + e]), up = g_rnd<T>(acc[a][j][8 + 4 * h + e]);
+                            o[e] = g_rnd<T>(gt / (1.f + __expf(-gt))) * up;
+                        }
+                        u32x2 w;
+                        w[0] = pack2<T>(o[0], o[1]);
+                        w[1] = pack2<T>(o[2], o[3]);
+                        *reinterpret_cast<u32x2*>(dst + 8 * h) = w;
+                    }
+                }
+            }
+        }
+    } else if (g.n_split == 1) {
+        // stage [BM][BN] in the model dtype, then whole-row 16-byte stores
+        constexpr int RS = BN * 2 + 16;
+        unsigned char* stg = smem;
+        if (computes)
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                u32x2 w;
+                w[0] = pack2<T>(acc[a][j][4 * g4 + 0], acc[a][j][4 * g4 + 1]);
+                w[1] = pack2<T>(acc[a][j][4 * g4 + 2], acc[a][j][4 * g4 + 3]);
+                *reinterpret_cast<u32x2*>(stg + ((mw * MT + a) * 32 + ql) * RS + ((ng * NT + j) * 32 + 8 * g4 + 4 * hi) * 2) = w;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        g_barrier();
+        constexpr int CPR = BN * 2 / 16;
+        for (int idx = tid; idx < BM * CPR; idx += G_THREADS) {
+            const int row = idx / CPR, c = idx % CPR;
+            if (m0 + row < g.M && n0 + c * 8 < g.N)
+                *reinterpret_cast<u32x4*>(g.C + (size_t)(m0 + row) * g.ldc + n0 + c * 8) = *reinterpret_cast<const u32x4*>(stg + row * RS + c * 16);
+        }
+    } else if (g.dbg & 32) {
+        // experiment (LADE_GEMM_DBG=32): fp32 partials straight from the accumulators - lane (m = ql, hi) of tile (a, j) holds the four
+        // consecutive weight rows n = 8*g4 + 4*hi .. +3 of activation row m, one 16-byte store each, no LDS staging and no barrier in
+        // the tail.  Measured the same or slower than the staged whole-row stores below (7B, 60 rows: 92.9 vs 90.4-92.2 us per layer;
+        // gate/up 40.2 vs 37.5-39.2): what the partial stores cost (16 us per layer, tools/gemm_flags.py with LADE_GEMM_DBG=1) is
+        // their 48.6 MB, not the staging round trip.
+        float* outp = g.Cpart + (size_t)split * g.M * g.N;
+        if (computes)
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            const int m = m0 + (mw * MT + a) * 32 + ql;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int nb = n0 + (ng * NT + j) * 32 + 4 * hi;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+                    if (m < g.M && nb + 8 * g4 < g.N)
+                        *reinterpret_cast<float4*>(outp + (size_t)m * g.N + nb + 8 * g4) =
+                            float4{acc[a][j][4 * g4 + 0], acc[a][j][4 * g4 + 1], acc[a][j][4 * g4 + 2], acc[a][j][4 * g4 + 3]};
+            }
+        }
+    } else {
+        // fp32 partials [split][M][N]; stage through LDS in two halves of BN to stay within the ring
+        constexpr int RSF = BN * 4 + 16;
+        float* outp = g.Cpart + (size_t)split * g.M * g.N;
+        unsigned char* stg = smem;
+        static_assert((size_t)BM * RSF <= (size_t)G_NSTAGE * STAGE, "fp32 staging must fit in the ring");
+        if (computes)
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                *reinterpret_cast<float4*>(stg + ((mw * MT + a) * 32 + ql) * RSF + ((ng * NT + j) * 32 + 8 * g4 + 4 * hi) * 4) =
+                    float4{acc[a][j][4 * g4 + 0], acc[a][j][4 * g4 + 1], acc[a][j][4 * g4 + 2], acc[a][j][4 * g4 + 3]};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        g_barrier();
+        constexpr int CPR = BN * 4 / 16;
+        for (int idx = tid; idx < BM * CPR; idx += G_THREADS) {
+            const int row = idx / CPR, c = idx % CPR;
+            if (m0 + row < g.M && n0 + c * 4 < g.N) {
+                const float4 v = *reinterpret_cast<const float4*>(stg + row * RSF + c * 16);
+                float* dstp = outp + (size_t)(m0 + row) * g.N + n0 + c * 4;
+                if (g.dbg & 8) {                       // experiment: write-through partial stores (nothing left dirty in L2 at the kernel boundary)
+                    const u32x4 vv = u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dstp), "v"(vv) : "memory");
+                }
+                else
+                    *reinterpret_cast<float4*>(dstp) = v;
+            }
+        }
+    }
+}
+
+// sums the n_split fp32 partials in split order and writes the model dtype:  C[m][n] = sum_s part[s][m][n]
+template <typename T, int MW, int MT, int NG, int NT>
+static int launch_gemm(const GemmK& g, hipStream_t st) {
+    constexpr int BN = 32 * NT * NG, BM = 32 * MW * MT;
+    constexpr size_t lds = (size_t)G_NSTAGE * (BN + BM) * 128;
+    static_assert(lds <= 160 * 1024, "LDS ring too large");
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<T, MW, MT, NG, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    dim3 grid(cdiv(g.N, BN), g.n_split, cdiv(g.M, BM));
+    hipLaunchKernelGGL((gemm_skinny_kernel<T, MW, MT, NG, NT>), grid, dim3(G_THREADS), lds, st, g);
+    return check_launch("lade_gemm_skinny");
+}
+
+// the shapes that are built: (wave grid MW x NG, MT x NT MFMA tiles per wave)
+#define SHAPE(TT, MWv, MTv, NGv, NTv) if (mw == MWv && mt == MTv && ng == NGv && nt == NTv) return launch_gemm<TT, MWv, MTv, NGv, NTv>(g, st);
+#define GO(TT)                                                                                                               \
+    /* 32 rows */  SHAPE(TT,1,1,1,1) SHAPE(TT,1,1,2,1) SHAPE(TT,1,1,4,1) SHAPE(TT,1,1,8,1) SHAPE(TT,1,1,2,2) SHAPE(TT,1,1,4,2) SHAPE(TT,1,1,3,1)  \
+    /* 64 rows */  SHAPE(TT,2,1,1,1) SHAPE(TT,2,1,2,1) SHAPE(TT,2,1,4,1) SHAPE(TT,2,1,3,2) SHAPE(TT,2,1,4,2) SHAPE(TT,2,1,3,1) SHAPE(TT,1,2,3,1)  \
+                   SHAPE(TT,1,2,2,1) SHAPE(TT,1,2,4,1) SHAPE(TT,1,2,6,1) SHAPE(TT,1,2,8,1) SHAPE(TT,1,2,2,2) SHAPE(TT,1,2,3,2)  \
+                   SHAPE(TT,1,2,4,2) SHAPE(TT,1,2,2,3) SHAPE(TT,1,2,2,4)                                                       \
+    /* 96 rows */  SHAPE(TT,3,1,1,1) SHAPE(TT,3,1,2,1) SHAPE(TT,3,1,2,2) SHAPE(TT,3,1,2,3) SHAPE(TT,3,1,2,4) SHAPE(TT,1,3,3,1)  \
+                   SHAPE(TT,1,3,4,1) SHAPE(TT,1,3,6,1) SHAPE(TT,1,3,8,1) SHAPE(TT,1,3,3,2) SHAPE(TT,1,3,4,2)                    \
+    /* 128 rows */ SHAPE(TT,4,1,1,1) SHAPE(TT,4,1,2,1) SHAPE(TT,4,1,2,2) SHAPE(TT,4,1,2,3) SHAPE(TT,4,1,2,4) SHAPE(TT,1,4,3,1) SHAPE(TT,2,2,3,1)  \
+                   SHAPE(TT,2,2,2,1) SHAPE(TT,2,2,4,1) SHAPE(TT,2,2,3,2) SHAPE(TT,2,2,4,2) SHAPE(TT,2,2,2,2)                    \
+                   SHAPE(TT,1,4,4,1) SHAPE(TT,1,4,6,1) SHAPE(TT,1,4,8,1) SHAPE(TT,1,4,3,2) SHAPE(TT,1,4,4,2) SHAPE(TT,1,4,2,2)                    \
+    /* 192 rows */ SHAPE(TT,2,3,2,1) SHAPE(TT,2,3,4,1) SHAPE(TT,2,3,2,2) SHAPE(TT,3,2,2,1) SHAPE(TT,3,2,2,2)                                     \
+    /* 256 rows */ SHAPE(TT,2,4,2,1) SHAPE(TT,2,4,4,1) SHAPE(TT,2,4,2,2) SHAPE(TT,4,2,2,1) SHAPE(TT,4,2,2,2)
+
+// -1: no kernel for this wave grid
+template <typename T>
+static int gemm_dispatch(const GemmK& g, hipStream_t st, int mw, int mt, int ng, int nt) {
+    GO(T)
+    return -1;
+}
+#undef GO
+#undef SHAPE
+
+}  // namespace lade

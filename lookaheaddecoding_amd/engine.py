@@ -289,14 +289,11 @@ class StepEngine:
         if name == "wgu" and os.environ.get("LADE_GU_TAIL_FIXED"):          # experiment: the flat 6 us estimate
             tail = lambda out_bytes: 0.006
         t_lib = time_it(lambda i: torch.matmul(a, ws[i % len(ws)].t(), out=out)) + 0.003 + tail(Mrows * N * 2)      # + the consumer's extra read
-        best, t_best = None, t_lib
-        log = [] if os.environ.get("LADE_TUNE_VERBOSE") else None        # tools/gemm_tune_probe.py: every candidate's time
+        timed = []                        # (ms incl. the consumer tail, (mb, bn, S, mt, nt))
         for (mb, bn, S, mt, nt) in cands:
             t = time_it(lambda i: ops.gemm_parts(a, ws[i % len(ws)], self.ws_part, S, bn, mb, mt, nt)) + tail(S * Mrows * N * 4)
-            if log is not None:
-                log.append((t, (mb, bn, S, mt, nt)))
-            if t < t_best:
-                best, t_best = (mb, bn, S, mt, nt), t
+            timed.append((t, (mb, bn, S, mt, nt)))
+        act = None
         if name == "wgu" and self.gu_layout == 1:
             # no split-K: BN weight rows x the whole K per work-group, SwiGLU in the epilogue, output in the model dtype.  Needs
             # N / BN work-groups to cover the CUs on their own: 96-row blocks at the 7B / 13B widths.
@@ -310,13 +307,13 @@ class StepEngine:
                         t = time_it(lambda i: ops.gemm_swiglu(a, ws[i % len(ws)], act, bn, mbs, mt, 1))
                     except cabi.LadeHipError:
                         continue                      # wave grid not built for this row class
-                    if log is not None:
-                        log.append((t, (mbs, bn, 1, mt, 1)))
-                    if t < t_best:
-                        best, t_best = (mbs, bn, 1, mt, 1), t
-        if log is not None:
+                    timed.append((t, (mbs, bn, 1, mt, 1)))
+        best, t_best = None, t_lib
+        if timed and min(timed)[0] < t_lib:
+            t_best, best = min(timed)
+        if os.environ.get("LADE_TUNE_VERBOSE"):          # tools/gemm_tune_probe.py: what the tuner saw
             mbytes = N * K * ws[0].element_size() / 1e6
-            top = " ".join(f"{c}:{t * 1e3:.1f}" for t, c in sorted(log)[:5])
+            top = " ".join(f"{c}:{t * 1e3:.1f}" for t, c in sorted(timed)[:6])
             print(f"[tune] {name}:{mclass} rows={Mrows} N={N} K={K} lib {t_lib * 1e3:.1f} us | best {best} {t_best * 1e3:.1f} us "
                   f"({mbytes / (t_best * 1e3):.2f} TB/s) | {top}", file=sys.stderr, flush=True)
         return best
