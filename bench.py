@@ -78,6 +78,15 @@ def attn_algorithmic_bytes(cfg, T, P, elem=2):
     return elem * (2 * Hkv * (P + T) * d + 2 * H * T * d)
 
 
+def step_stream_bytes(cfg, P, n_logit_rows, elem=2):
+    """What one decode step must read from HBM whatever T is: every layer's projection weights once, the K/V cache of every layer,
+    the lm_head (its rows are all needed as soon as one logits row is).  Activations, partials and the new K/V rows are not counted."""
+    h, inter, L, H, Hkv, d, V = cfg["hidden"], cfg["inter"], cfg["layers"], cfg["heads"], cfg["kv_heads"], cfg["head_dim"], cfg["vocab"]
+    per_layer = ((H + 2 * Hkv) * d * h + H * d * h + 3 * inter * h) * elem
+    kv = 2 * Hkv * P * d * elem
+    return L * (per_layer + kv) + (V * h * elem if n_logit_rows else 0)
+
+
 def attn_useful_flops(cfg, T, P, W, N, g):
     """K1 useful flops = 4*d*H*(T*P + vis), vis = visible (query, new key) pairs of the closed-form mask"""
     gs = N - 1
@@ -496,7 +505,12 @@ def worker(args):
             "prefill": {"tokens": args.prompt_len + W + N - 3, "ms": round(prefill_s * 1e3, 2), "tokens_per_s": round((args.prompt_len + W + N - 3) / prefill_s, 1),
                         "how": f"prompt + first window level as causal chunks of <= {args.chunk} rows through the same attention / GEMM kernels, lm_head on the "
                                "rows that are read only; second prefill of the process (the first one pays the one-off GEMM autotune)"},
-            "hot_regime": hot, "plain_decode": plain, "roofline": roofline, "cpu_baseline": cpu,
+            "hot_regime": hot, "plain_decode": plain, "roofline": roofline,
+            # the whole step against the same HBM peak: the bytes a step cannot avoid reading (weights + K/V cache + lm_head) / its time
+            "step_stream": {"bound": "hbm", "bytes_per_step": step_stream_bytes(cfg, P_end, 1), "achieved": round(step_stream_bytes(cfg, P_end, 1) / (elapsed / args.steps) / 1e9, 1),
+                            "peak": 8000.0, "unit": "GB/s", "frac": round(step_stream_bytes(cfg, P_end, 1) / (elapsed / args.steps) / 1e9 / 8000.0, 4),
+                            "note": "per rank; unavoidable reads of one decode step (every projection weight, the K/V cache, the lm_head) / ms_per_step"},
+            "cpu_baseline": cpu,
         }
     if use_lp:
         dist.barrier()
