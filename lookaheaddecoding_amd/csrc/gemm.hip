@@ -55,7 +55,7 @@ extern "C" int lade_gemm_skinny(const void* A, int64_t lda, const void* W, int64
     LADE_REQUIRE(mb >= 1 && mb <= 8 && mt >= 1 && mt <= 4 && mb % mt == 0, LADE_E_ARG, "lade_gemm_skinny: mb=%d mt=%d", mb, mt);
     if (mb > 4 && bn > 128) bn = 128;      // 192 / 256-row work-groups: the activation tile leaves room for <= 128 weight rows per stage
     const int mw = mb / mt;
-    const int tiles = bn <= 32 ? 1 : (bn <= 64 ? 2 : (bn <= 96 ? 3 : (bn <= 128 ? 4 : (bn <= 192 ? 6 : 8))));      // 32-row weight tiles per work-group
+    const int tiles = bn <= 32 ? 1 : (bn <= 64 ? 2 : (bn <= 96 ? 3 : (bn <= 128 ? 4 : (bn <= 192 ? 6 : (bn <= 224 ? 7 : 8)))));      // 32-row weight tiles per work-group
     if (nt == 0) {                                     // default: as many n-groups as waves allow
         const int ng_max = 8 / mw;
         nt = 1;

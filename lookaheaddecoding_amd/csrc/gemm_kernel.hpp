@@ -287,6 +287,8 @@ static int launch_gemm(const GemmK& g, hipStream_t st) {
     /* 128 rows */ SHAPE(TT,4,1,1,1) SHAPE(TT,4,1,2,1) SHAPE(TT,4,1,2,2) SHAPE(TT,4,1,2,3) SHAPE(TT,4,1,2,4) SHAPE(TT,1,4,3,1) SHAPE(TT,2,2,3,1)  \
                    SHAPE(TT,2,2,2,1) SHAPE(TT,2,2,4,1) SHAPE(TT,2,2,3,2) SHAPE(TT,2,2,4,2) SHAPE(TT,2,2,2,2)                    \
                    SHAPE(TT,1,4,4,1) SHAPE(TT,1,4,6,1) SHAPE(TT,1,4,8,1) SHAPE(TT,1,4,3,2) SHAPE(TT,1,4,4,2) SHAPE(TT,1,4,2,2)                    \
+    /* 224-row weight blocks (N = 57344 = 256 x 224: Llama-2-70B gate/up on 256 CUs in one wave of work-groups) */        \
+                   SHAPE(TT,1,1,7,1) SHAPE(TT,1,2,7,1) SHAPE(TT,1,3,7,1) SHAPE(TT,1,4,7,1)                                      \
     /* 192 rows */ SHAPE(TT,2,3,2,1) SHAPE(TT,2,3,4,1) SHAPE(TT,2,3,2,2) SHAPE(TT,3,2,2,1) SHAPE(TT,3,2,2,2)                                     \
     /* 256 rows */ SHAPE(TT,2,4,2,1) SHAPE(TT,2,4,4,1) SHAPE(TT,2,4,2,2) SHAPE(TT,4,2,2,1) SHAPE(TT,4,2,2,2)
 

@@ -299,7 +299,7 @@ class StepEngine:
             # N / BN work-groups to cover the CUs on their own: 96-row blocks at the 7B / 13B widths.
             act = torch.empty(a.shape[0], N // 2, dtype=self.dtype, device=self.device)
             mbs = {32: 1, 64: 2, 96: 3, 128: 4, 192: 6, 256: 8}[mclass]
-            for bn in (64, 96, 128):
+            for bn in (64, 96, 128) + ((224,) if N % 224 == 0 else ()):        # 224: N = 256 x 224 at the 70B width
                 for mt in sorted({1, 2 if mbs % 2 == 0 else 1, mbs if mbs <= 4 else mbs // 2}):
                     if mbs % mt or (mbs // mt) * (bn // 32) > 8:
                         continue

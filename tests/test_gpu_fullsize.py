@@ -133,6 +133,7 @@ def test_skinny_gemm_vs_fp32_reference():
                                     (2, 128, 1, 1, 2), (3, 256, 1, 1, 2), (2, 192, 3, 3, 2), (1, 256, 3, 3, 2), (2, 128, 3, 3, 0), (2, 192, 4, 4, 2),
                                     (3, 256, 4, 4, 2), (1, 128, 4, 4, 2), (2, 128, 4, 2, 2),
                                     # 192 / 256-row work-groups (steps of up to 256 tokens: the weights are streamed once)
+                                    (1, 224, 2, 2, 1), (2, 224, 1, 1, 1), (3, 224, 4, 4, 1),      # 7-tile weight blocks
                                     (2, 128, 8, 4, 1), (4, 64, 8, 4, 1), (1, 128, 8, 4, 2), (3, 64, 8, 2, 1), (2, 128, 8, 2, 2), (2, 128, 6, 3, 1), (3, 64, 6, 3, 1),
                                     (2, 128, 6, 3, 2), (2, 64, 6, 2, 1), (1, 128, 6, 2, 2), (2, 128, 0, 0, 0)]:
             if K // 64 < S:

@@ -510,7 +510,7 @@ def test_gate_up_gemm_with_swiglu_epilogue_and_interleaved_layout():
     layout-1 SwiGLU kernels (plain and split-K partials) against layout 0 on the same values."""
     from lookaheaddecoding_amd import ops
     torch.manual_seed(5)
-    for (M, inter, K) in ((60, 11008, 4096), (16, 256, 128), (120, 1408, 512), (33, 176, 64)):
+    for (M, inter, K) in ((60, 11008, 4096), (16, 256, 128), (120, 1408, 512), (33, 176, 64), (31, 1792, 1024)):      # 2 * 1792 = 16 blocks of 224 rows
         a = torch.randn(M, K, device="cuda").bfloat16()
         wg = (torch.randn(inter, K, device="cuda") * 0.05).bfloat16()
         wu = (torch.randn(inter, K, device="cuda") * 0.05).bfloat16()
@@ -520,7 +520,7 @@ def test_gate_up_gemm_with_swiglu_epilogue_and_interleaved_layout():
         ref = torch.nn.functional.silu(g) * u
         gu = a @ w.t()                                   # fused, interleaved columns
         two_kernel = ops.silu_mul(gu.contiguous(), layout=1)
-        for (bn, mb, mt) in ((96, 0, 1), (64, 0, 1), (128, 0, 2), (96, 0, 2)):
+        for (bn, mb, mt) in ((96, 0, 1), (64, 0, 1), (128, 0, 2), (96, 0, 2), (224, 0, 1), (224, 0, 2), (224, 0, 4)):
             out = torch.full((M, inter), float("nan"), dtype=torch.bfloat16, device="cuda")
             mb = 1 if M <= 32 else 2 if M <= 64 else 3 if M <= 96 else 4
             if mb % mt:
