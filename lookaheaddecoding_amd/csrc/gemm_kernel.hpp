@@ -252,6 +252,8 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
                     const u32x4 vv = u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
                     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dstp), "v"(vv) : "memory");
                 }
+                else if (g.dbg & 64)                   // experiment: non-temporal partial stores (faster GEMM, slower consumer: DESIGN 4.6)
+                    __builtin_nontemporal_store(u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, reinterpret_cast<u32x4*>(dstp));
                 else
                     *reinterpret_cast<float4*>(dstp) = v;
             }
