@@ -24,3 +24,23 @@ def test_committed_bench_line_has_the_contract_fields():
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1
     assert abs(d["value"] - d["step_compression"] * 1e3 / d["ms_per_step"]) / d["value"] < 0.02      # tokens/s = S / step time
+
+
+def test_step_stream_bytes_model_and_the_committed_figure():
+    """bench.py's `step_stream`: the bytes a decode step cannot avoid reading.  The byte model against the 7B shape by hand, and the
+    committed line consistent with it (achieved = bytes / ms_per_step, frac = achieved / peak)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cfg = dict(hidden=4096, inter=11008, layers=32, heads=32, kv_heads=32, head_dim=128, vocab=32000)
+    per_layer = (3 * 4096 * 4096 + 4096 * 4096 + 3 * 11008 * 4096) * 2                   # qkv, o, gate / up / down in bf16
+    kv = 2 * 32 * 2091 * 128 * 2
+    assert bench.step_stream_bytes(cfg, 2091, 1) == 32 * (per_layer + kv) + 32000 * 4096 * 2
+    assert bench.step_stream_bytes(cfg, 2091, 0) == 32 * (per_layer + kv)
+    with open(os.path.join(ROOT, "profiles", "r2_bench.json")) as f:
+        d = json.loads([l for l in f.read().splitlines() if l.strip().startswith("{")][-1])
+    s = d["step_stream"]
+    assert s["bound"] == "hbm" and s["unit"] == "GB/s" and s["peak"] == 8000.0
+    assert abs(s["achieved"] - s["bytes_per_step"] / (d["ms_per_step"] * 1e-3) / 1e9) / s["achieved"] < 0.01
+    assert abs(s["frac"] - s["achieved"] / s["peak"]) < 1e-3 and 0.0 < s["frac"] < 1.0
