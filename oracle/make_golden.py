@@ -331,6 +331,24 @@ def gen_e2e_greedy():
 
 
 
+def gen_e2e_greedy_wide():
+    """BASELINE config 4's lookahead parameters (W = 20, N = 7, G = 20: steps of up to 6 * (20 + 20) = 240 tokens, six-token n-grams,
+    the long-guess verification branch) on the tiny models, with and without POOL_FROM_PROMPT.  A separate fixture so that
+    e2e_greedy.json stays byte-identical."""
+    runs = []
+    for (mname, pname, W, N, G, new, seed, pfp) in [("tiny-d128", "rep", 20, 7, 20, 48, 1, 1), ("tiny-d64", "rep2", 20, 7, 20, 40, 2, 0)]:
+        cfg, w, model = get_model(mname)
+        prompt = [t % cfg["vocab"] for t in PROMPTS[pname]]
+        plain = plain_greedy_hf(model, prompt, len(prompt) + new)
+        toks, steps, gen, rec = run_ref_greedy(model, prompt, W, N, G, len(prompt) + new, seed, pfp, None, ())
+        runs.append({"model": mname, "model_seed": MODELS[mname]["seed"], "std": MODELS[mname]["std"], "prompt": prompt, "W": W, "N": N, "G": G,
+                     "max_length": len(prompt) + new, "seed": seed, "pool_from_prompt": pfp, "eos": None, "tokens": toks,
+                     "steps": steps, "generated": gen, "equals_plain_greedy": toks == plain[:len(toks)], "plain": plain, "trace": rec.steps})
+        print("wide", mname, pname, W, N, G, "seed", seed, "steps", steps, "gen", gen, "S", round(gen / steps, 2), "plain==", toks == plain[:len(toks)],
+              "max T", max(len(st["ids"]) for st in rec.steps))
+    dump("e2e_greedy_wide.json", {"runs": runs})
+
+
 def gen_e2e_unlimited():
     """GUESS_SET_SIZE = -1 ("unlimited" pool): both reference loops gate the verification branch on GUESS_SET_SIZE > 0
     (lade/decoding.py:402, :948), so the pool is only written - one token per step.  Small separate fixture."""
@@ -508,5 +526,7 @@ if __name__ == "__main__":
         gen_e2e_lp()
     if "unlimited" in what:
         gen_e2e_unlimited()
+    if "greedy_wide" in what:          # not in the default list: added in round 2 without regenerating the other fixtures
+        gen_e2e_greedy_wide()
     if "sample_eos" in what:
         gen_e2e_sample_eos()

@@ -112,7 +112,9 @@ def _check_trace(res, run, rank_traces=None):
 def test_greedy_e2e_matches_reference_traces():
     d = load("e2e_greedy.json")
     assert len(d["runs"]) >= 10
-    for run in d["runs"]:
+    wide = load("e2e_greedy_wide.json")["runs"]          # BASELINE config 4's W = 20, N = 7, G = 20 (steps of up to 240 tokens)
+    assert len(wide) == 2 and max(len(st["ids"]) for r in wide for st in r["trace"]) == 240
+    for run in d["runs"] + wide:
         model = oracle_model(run)
         res = O.lookahead_greedy(model, run["prompt"], run["W"], run["N"], run["G"], run["max_length"], random.Random(run["seed"]),
                                  eos_token_id=run["eos"], pool_from_prompt=bool(run["pool_from_prompt"]))
