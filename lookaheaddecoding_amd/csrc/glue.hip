@@ -82,9 +82,27 @@ template <typename T, int N, int R>
 __device__ __forceinline__ void load_parts_r(const float* parts, int n_parts, size_t part_stride, size_t idx, float* out) {
 #pragma unroll
     for (int e = 0; e < N; ++e) out[e] = 0.f;
-    // R partials per round: all their loads are in flight together (these kernels are latency bound); the
-    // summation order stays 0,1,2,...
-    for (int s0 = 0; s0 < n_parts; s0 += R) {
+    // R partials per round: all their loads are in flight together (these kernels are latency bound); the summation order stays
+    // 0,1,2,...  The first round is straight-line code (no loop header in front of its loads: the compiler puts a wait for the
+    // caller's earlier loads in front of a loop, which serialises two memory latencies); further rounds (n_parts > R) loop.
+    {
+        float4 v[R][N / 4];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const float* p = parts + (size_t)min(j, n_parts - 1) * part_stride + idx;
+#pragma unroll
+            for (int e = 0; e < N / 4; ++e) v[j][e] = *reinterpret_cast<const float4*>(p + 4 * e);
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+            if (j < n_parts) {                                     // a partial past the end was the last one again: not added
+#pragma unroll
+                for (int e = 0; e < N / 4; ++e) {
+                    out[4 * e] += v[j][e].x; out[4 * e + 1] += v[j][e].y; out[4 * e + 2] += v[j][e].z; out[4 * e + 3] += v[j][e].w;
+                }
+            }
+    }
+    for (int s0 = R; s0 < n_parts; s0 += R) {
         float4 v[R][N / 4];
 #pragma unroll
         for (int j = 0; j < R; ++j) {
@@ -134,11 +152,14 @@ __global__ __launch_bounds__(BT) void rmsnorm_kernel(typename St<T>::S* x, const
         const int i = threadIdx.x + c * BT;
         if (i < nvec) {
             wv[c] = *reinterpret_cast<const u32x4*>(w + (size_t)i * N);
-            unpack<T>(*reinterpret_cast<const u32x4*>(x + base + (size_t)i * N), v[c]);
+            const u32x4 xr = *reinterpret_cast<const u32x4*>(x + base + (size_t)i * N);      // used only after the partial loads are in flight
+            float rr[N];
             if (ADD) {
-                float rr[N];
                 if (parts) load_parts<T, N>(parts, n_parts, part_stride, base + (size_t)i * N, rr);
                 else unpack<T>(*reinterpret_cast<const u32x4*>(r + base + (size_t)i * N), rr);
+            }
+            unpack<T>(xr, v[c]);
+            if (ADD) {
 #pragma unroll
                 for (int e = 0; e < N; ++e) v[c][e] = rnd_st<T>(v[c][e] + rr[e]);
                 *reinterpret_cast<u32x4*>(x + base + (size_t)i * N) = repack<T>(v[c]);

@@ -62,12 +62,19 @@ __global__ __launch_bounds__(256) void rope_kv_append_kernel(typename Elem<T>::S
                 const int h = idx / vph, i = (idx - h * vph) * VEC;
                 S* x = row + (size_t)h * d;
                 S x1[VEC], x2[VEC], c1[VEC], c2[VEC], s1[VEC], s2[VEC], o1[VEC], o2[VEC];
+                // the cos / sin rows depend on the position only: requested before the partials are waited for (one memory latency
+                // instead of two)
+                *reinterpret_cast<uint4*>(c1) = *reinterpret_cast<const uint4*>(c + i);
+                *reinterpret_cast<uint4*>(c2) = *reinterpret_cast<const uint4*>(c + i + half);
+                *reinterpret_cast<uint4*>(s1) = *reinterpret_cast<const uint4*>(s + i);
+                *reinterpret_cast<uint4*>(s2) = *reinterpret_cast<const uint4*>(s + i + half);
                 if (parts) {                       // qkv arrives as split-K fp32 partials: sum, round once to the dtype
                     const size_t e0 = (size_t)t * row_w + (size_t)h * d + i;
                     float a[VEC], b[VEC];
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) { a[e] = 0.f; b[e] = 0.f; }
                     // rounds of 8 partials: every load of a round is in flight before the first add (order 0,1,2,..)
+#pragma unroll 1
                     for (int s0 = 0; s0 < n_parts; s0 += 8) {
                         float4 va[8][VEC / 4], vb[8][VEC / 4];
 #pragma unroll
@@ -95,10 +102,6 @@ __global__ __launch_bounds__(256) void rope_kv_append_kernel(typename Elem<T>::S
                     *reinterpret_cast<uint4*>(x1) = *reinterpret_cast<const uint4*>(x + i);
                     *reinterpret_cast<uint4*>(x2) = *reinterpret_cast<const uint4*>(x + i + half);
                 }
-                *reinterpret_cast<uint4*>(c1) = *reinterpret_cast<const uint4*>(c + i);
-                *reinterpret_cast<uint4*>(c2) = *reinterpret_cast<const uint4*>(c + i + half);
-                *reinterpret_cast<uint4*>(s1) = *reinterpret_cast<const uint4*>(s + i);
-                *reinterpret_cast<uint4*>(s2) = *reinterpret_cast<const uint4*>(s + i + half);
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     const float a1 = Elem<T>::ld(x1[e]), a2 = Elem<T>::ld(x2[e]);
