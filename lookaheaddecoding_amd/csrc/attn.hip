@@ -561,6 +561,11 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnK a, int D) {
             v[j] = *reinterpret_cast<const float2*>(ml + s * ml_stride);
             o[j] = *reinterpret_cast<const u32x4*>(po + s * po_stride);
         }
+        // pin the (m, l) loads here: left alone, the compiler sinks each of them into the `s0 + j < ns` branch that first uses it,
+        // one dependent memory latency after the other (five in a row at 8 splits)
+        __builtin_amdgcn_sched_barrier(0);               // ... and keep all sixteen loads in front of the first wait
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(v[j].x), "+v"(v[j].y));
         float gm = mx;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
