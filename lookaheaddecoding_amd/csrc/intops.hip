@@ -284,18 +284,31 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(const void* logits, i
     int vend = 0;
     if (aligned) {
         vend = (V / VEC) * VEC;
-        for (int i = threadIdx.x * VEC; i < vend; i += 1024 * VEC) {
-            const uint4 u = *reinterpret_cast<const uint4*>((const char*)logits + (base + i) * ebytes);
-            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-            if (is16) {
+        // four 16-byte loads of a thread in flight at a time (a row of 32000 logits is four strides of the block: one memory latency
+        // instead of four)
+        for (int i0 = threadIdx.x * VEC; i0 < vend; i0 += 4 * 1024 * VEC) {
+            uint4 uu[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    upd(to_f32<typename std::conditional<is16, T, BF16>::type>((uint16_t)(w[e] & 0xffffu)), i + 2 * e);
-                    upd(to_f32<typename std::conditional<is16, T, BF16>::type>((uint16_t)(w[e] >> 16)), i + 2 * e + 1);
+            for (int k = 0; k < 4; ++k) {
+                const int i = min(i0 + k * 1024 * VEC, vend - VEC);          // past the end: the row's last chunk again (not used)
+                uu[k] = *reinterpret_cast<const uint4*>((const char*)logits + (base + i) * ebytes);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * 1024 * VEC;
+                if (i < vend) {
+                    const uint32_t w[4] = {uu[k].x, uu[k].y, uu[k].z, uu[k].w};
+                    if (is16) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            upd(to_f32<typename std::conditional<is16, T, BF16>::type>((uint16_t)(w[e] & 0xffffu)), i + 2 * e);
+                            upd(to_f32<typename std::conditional<is16, T, BF16>::type>((uint16_t)(w[e] >> 16)), i + 2 * e + 1);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) upd(__uint_as_float(w[e]), i + e);
+                    }
                 }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) upd(__uint_as_float(w[e]), i + e);
             }
         }
     }
