@@ -29,7 +29,7 @@
  *   lade_window_fill_first / lade_window_fill / lade_window_roll   lade/decoding.py:1038-1066, :1119-1124
  *   lade_greedy_post_step    the fused single-rank tail of one steady step: verify + pool insert +
  *                            roll + next lookup + control update   lade/decoding.py:1071-1130,1165
- *   lade_lp_unique_id / lade_lp_comm_create / lade_lp_allgather / lade_lp_comm_destroy   RCCL communicator + the step's one
+ *   lade_lp_unique_id / lade_lp_comm_create / lade_lp_allgather / lade_lp_comm_count / lade_lp_comm_destroy   RCCL communicator + the step's one
  *                            collective   lade/utils.py:28-33, lade/decoding.py:1024,1057,1090,1096,1106
  *   lade_lp_pack / lade_lp_reduce_apply   the per-step lookahead-parallel exchange record
  *                            lade/decoding.py:1023-1024, 1088-1107 (four pickled object collectives
@@ -251,11 +251,15 @@ int lade_lp_reduce_apply(const int32_t* all_rec, int32_t R, int32_t rec_words, i
  *                        the library; one handle per rank / process
  *   lade_lp_allgather    recv[r*words .. ] = rank r's send[0..words): ordered on `stream` (after lade_lp_pack, before
  *                        lade_lp_reduce_apply), in place allowed when send == recv + rank*words
- *   lade_lp_comm_destroy explicit release
+ *   lade_lp_comm_count   number of ranks the communicator spans (ncclCommCount) - what `dist.get_world_size()` is for a caller of the
+ *                        reference (lade/utils.py:33 asserts it against DIST_WORKERS); lade_lp_comm_create already refuses a
+ *                        communicator whose span differs from `world`
+ *   lade_lp_comm_destroy explicit release (the handle is freed even when RCCL reports an error)
  * Without an RCCL library in the process they return LADE_E_LIMIT. */
 int lade_lp_unique_id(void* id128);
 int lade_lp_comm_create(const void* id128, int32_t rank, int32_t world, void** comm_out);
 int lade_lp_allgather(void* comm, const int32_t* send, int32_t* recv, int32_t words_per_rank, void* stream);
+int lade_lp_comm_count(void* comm, int32_t* ranks_out);
 int lade_lp_comm_destroy(void* comm);
 
 /* ---- sampling helpers ------------------------------------------------------------------ */

@@ -73,6 +73,7 @@ SIGNATURES = {
     "lade_lp_unique_id": [_vp],
     "lade_lp_comm_create": [_vp, _i32, _i32, C.POINTER(_vp)],
     "lade_lp_allgather": [_vp, _vp, _vp, _i32, _vp],
+    "lade_lp_comm_count": [_vp, C.POINTER(_i32)],
     "lade_lp_comm_destroy": [_vp],
     "lade_softmax_rows": [_vp, _i64, _i32, _i32, _i32, _f32, _vp, _vp],
     "lade_softmax_gather": [_vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],

@@ -7,8 +7,8 @@
 //
 // Shape of the problem: T <= ~256 query tokens against P+T keys, per KV head.  It is HBM-bound
 // (arithmetic intensity ~ T*H/Hkv flop/B, below the gfx950 ridge for MHA), so the kernel is a
-// split-KV streaming kernel:  grid = (row blocks of 128, KV heads, KV splits), 4 waves per block,
-// each wave owns 32 query rows, all four share the K / V^T tiles staged in LDS.
+// split-KV streaming kernel:  grid = (row blocks, KV heads, KV splits); a work-group is RG x KQ waves (default 4 x 2 = 8 waves,
+// 128 query rows): wave (rg, kq) owns 32 query rows and a 32-key part of every tile, all share the K / V^T tiles staged in LDS.
 //
 // Everything is computed "transposed" so that a lane owns ONE query row end to end:
 //     S^T[key][q] = K[key][:] . Q[q][:]           A = K tile (LDS),   B = Q^T (registers)
@@ -191,8 +191,9 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // rg / kq from the wave index: waves w and w+4 share a SIMD (dispatch order 0,2,1,3,0,2,1,3); with RG=4 and T <= 64 rows the
 // four busy waves sit on four different SIMDs, and with more rows every SIMD interleaves two waves - one in its MFMA phase
 // while the other waits on LDS or runs the softmax VALU work.
-// KV split sp of n_splits takes the 64-key tiles sp, sp+n_splits, sp+2*n_splits, ...: the splits differ by at most one tile
-// whatever the cache length is.  The KQ key parts keep separate online-softmax states and are merged through LDS at the end.
+// KV split sp of n_splits takes a CONTIGUOUS range of ceil(tiles / n_splits) 64-key tiles (the interleaved assignment sp, sp+n, ...
+// is kept behind LADE_ATTN_DBG=64: it balances perfectly but loses DRAM locality, +1.6 us at the 7B shape).  The KQ key parts keep
+// separate online-softmax states and are merged through LDS at the end.
 template <typename T, int D, int RG, int KQ>
 __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
     constexpr int NW = RG * KQ;                    // waves

@@ -14,43 +14,51 @@
 #include <dlfcn.h>
 #include <string.h>
 
+#include <mutex>
+#include <string>
+
+#include <rccl/rccl.h>        // types, enums and prototypes only: the entry points are resolved at run time (see above), nothing links librccl
+
 #include "common.hpp"
 
 namespace {
 
-typedef int ncclResult_t;                      // ncclSuccess == 0
-typedef struct { char internal[128]; } ncclUniqueId;      // NCCL_UNIQUE_ID_BYTES
-typedef void* ncclComm_t;
-constexpr int ncclInt32 = 2;                   // ncclDataType_t: ncclInt8 0, ncclUint8 1, ncclInt32 2
-
 struct Rccl {
     void* h = nullptr;
-    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
-    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
     bool ok = false;
+    std::string why;          // dlopen / dlsym failure text, captured once (dlerror() clears itself when read)
 };
 
+// bound once per process, thread-safe: lookahead-parallel ranks may be threads of one process (tests)
 Rccl& rccl() {
     static Rccl r;
-    static bool tried = false;
-    if (tried) return r;
-    tried = true;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) {
-        r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);       // an instance the process already carries (torch's) wins
-        if (r.h) break;
-    }
-    for (int i = 0; !r.h && i < 3; ++i) r.h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
-    if (!r.h) return r;
-    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
-    r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
-    r.AllGather = (decltype(r.AllGather))dlsym(r.h, "ncclAllGather");
-    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
-    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
-    r.ok = r.GetUniqueId && r.CommInitRank && r.AllGather && r.CommDestroy;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);       // an instance the process already carries (torch's) wins
+            if (r.h) break;
+        }
+        for (int i = 0; !r.h && i < 3; ++i) {
+            r.h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+            if (!r.h) { const char* e = dlerror(); if (e) r.why = e; }
+        }
+        if (!r.h) { if (r.why.empty()) r.why = "librccl.so.1 not found"; return; }
+        r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
+        r.AllGather = (decltype(r.AllGather))dlsym(r.h, "ncclAllGather");
+        r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
+        r.CommCount = (decltype(r.CommCount))dlsym(r.h, "ncclCommCount");
+        r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+        r.ok = r.GetUniqueId && r.CommInitRank && r.AllGather && r.CommDestroy && r.CommCount;
+        if (!r.ok) r.why = "missing symbols in librccl";
+    });
     return r;
 }
 
@@ -65,14 +73,14 @@ const char* err_text(Rccl& r, ncclResult_t e) { return r.GetErrorString ? r.GetE
 
 #define RCCL_OR_FAIL(what)                                                                                     \
     Rccl& R = rccl();                                                                                          \
-    LADE_REQUIRE(R.ok, LADE_E_LIMIT, what ": RCCL (librccl.so.1) is not available in this process: %s", dlerror() ? dlerror() : "missing symbols")
+    LADE_REQUIRE(R.ok, LADE_E_LIMIT, what ": RCCL (librccl.so.1) is not available in this process: %s", R.why.c_str())
 
 extern "C" int lade_lp_unique_id(void* id128) {
     LADE_REQUIRE(id128, LADE_E_ARG, "lade_lp_unique_id: null buffer");
     RCCL_OR_FAIL("lade_lp_unique_id");
     ncclUniqueId id;
     const ncclResult_t e = R.GetUniqueId(&id);
-    LADE_REQUIRE(e == 0, LADE_E_LAUNCH, "lade_lp_unique_id: %s", err_text(R, e));
+    LADE_REQUIRE(e == ncclSuccess, LADE_E_LAUNCH, "lade_lp_unique_id: %s", err_text(R, e));
     memcpy(id128, &id, sizeof(id));
     return LADE_OK;
 }
@@ -84,7 +92,14 @@ extern "C" int lade_lp_comm_create(const void* id128, int32_t rank, int32_t worl
     memcpy(&id, id128, sizeof(id));
     ncclComm_t c = nullptr;
     const ncclResult_t e = R.CommInitRank(&c, world, id, rank);      // binds to the calling thread's current HIP device (lade/utils.py:32)
-    LADE_REQUIRE(e == 0 && c, LADE_E_LAUNCH, "lade_lp_comm_create: ncclCommInitRank: %s", err_text(R, e));
+    LADE_REQUIRE(e == ncclSuccess && c, LADE_E_LAUNCH, "lade_lp_comm_create: ncclCommInitRank: %s", err_text(R, e));
+    // the communicator must span exactly the ranks the caller believes in: a mismatch (stale id, wrong world) fails here, loudly
+    int n = -1;
+    const ncclResult_t e2 = R.CommCount(c, &n);
+    if (e2 != ncclSuccess || n != world) {
+        (void)R.CommDestroy(c);
+        LADE_REQUIRE(false, LADE_E_LAUNCH, "lade_lp_comm_create: communicator spans %d ranks, expected %d (%s)", n, world, err_text(R, e2));
+    }
     *comm_out = new LpComm{c, rank, world};
     return LADE_OK;
 }
@@ -94,16 +109,27 @@ extern "C" int lade_lp_allgather(void* comm, const int32_t* send, int32_t* recv,
     RCCL_OR_FAIL("lade_lp_allgather");
     LpComm* lc = (LpComm*)comm;
     const ncclResult_t e = R.AllGather(send, recv, (size_t)words_per_rank, ncclInt32, lc->comm, (hipStream_t)stream);
-    LADE_REQUIRE(e == 0, LADE_E_LAUNCH, "lade_lp_allgather: %s", err_text(R, e));
+    LADE_REQUIRE(e == ncclSuccess, LADE_E_LAUNCH, "lade_lp_allgather: %s", err_text(R, e));
+    return LADE_OK;
+}
+
+extern "C" int lade_lp_comm_count(void* comm, int32_t* ranks_out) {
+    LADE_REQUIRE(comm && ranks_out, LADE_E_ARG, "lade_lp_comm_count: null argument");
+    RCCL_OR_FAIL("lade_lp_comm_count");
+    int n = 0;
+    const ncclResult_t e = R.CommCount(((LpComm*)comm)->comm, &n);
+    LADE_REQUIRE(e == ncclSuccess, LADE_E_LAUNCH, "lade_lp_comm_count: %s", err_text(R, e));
+    *ranks_out = n;
     return LADE_OK;
 }
 
 extern "C" int lade_lp_comm_destroy(void* comm) {
     if (!comm) return LADE_OK;
-    RCCL_OR_FAIL("lade_lp_comm_destroy");
     LpComm* lc = (LpComm*)comm;
-    const ncclResult_t e = R.CommDestroy(lc->comm);
-    delete lc;
-    LADE_REQUIRE(e == 0, LADE_E_LAUNCH, "lade_lp_comm_destroy: %s", err_text(R, e));
+    const ncclComm_t c = lc->comm;
+    delete lc;                                       // the handle is gone whatever happens below
+    RCCL_OR_FAIL("lade_lp_comm_destroy");
+    const ncclResult_t e = R.CommDestroy(c);
+    LADE_REQUIRE(e == ncclSuccess, LADE_E_LAUNCH, "lade_lp_comm_destroy: %s", err_text(R, e));
     return LADE_OK;
 }

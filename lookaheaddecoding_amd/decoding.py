@@ -293,9 +293,13 @@ class LookaheadDecoder:
         """`jacobi_greedy_search_multilevel` (lade/decoding.py:697-1259), single GPU or lookahead parallel.
         on_step(accepted_tokens): called after every step with the tokens it accepted (chat printing / HF streamers,
         lade/decoding.py:1179-1200)."""
-        if self.lp is not None and self.lp.R > 1:
+        if self.lp is not None and (self.lp.R > 1 or self.lp.force):
             from .parallel import greedy_lp
-            return greedy_lp(self, prompt, max_length, eos_token_id, rng, keep_trace, on_step=on_step)
+            out = greedy_lp(self, prompt, max_length, eos_token_id, rng, keep_trace, on_step=on_step)
+            # the reference logs on rank 0 only (`if DEBUG and LOCAL_RANK == 0`, lade/decoding.py:1231-1235)
+            if CONFIG_MAP.get("DEBUG", 0) and self.lp.rank == 0:
+                CONFIG_MAP.setdefault("log", []).append([out.generated, out.steps, round(out.generated / max(out.steps, 1), 2)])
+            return out
         self.start(prompt, eos_token_id, rng)
         trace: List[dict] = []
         while True:

@@ -6,15 +6,17 @@ LlamaDecoderLayer.forward -> LlamaAttention.forward (lade/models/modeling_llama.
 mask, a torch.cat of the whole KV cache per layer and lm_head over all T rows.  Here one step is
 
     ids/positions (built on device)  -> embedding row gather
-    per layer:  [add+]RMSNorm (HIP) -> fused QKV GEMM (hipBLASLt via torch)
-                -> RoPE + in-place KV append (HIP) -> lookahead attention (HIP, mask in-kernel)
-                -> O GEMM -> add+RMSNorm (HIP) -> fused gate/up GEMM -> SwiGLU (HIP) -> down GEMM
+    per layer:  [add+]RMSNorm (HIP) -> fused QKV GEMM -> RoPE + in-place KV append (HIP)
+                -> lookahead attention (HIP, mask in-kernel, split-KV + merge)
+                -> O GEMM -> add+RMSNorm (HIP) -> fused gate/up GEMM (+ SwiGLU) -> down GEMM
     needed rows only -> add+RMSNorm -> lm_head GEMM -> row argmax (HIP, int32 ids)
 
 with a preallocated KV cache ([L][2][Hkv*S_max*d]; keys row-major, values transposed) sized for
-the 288 GB of HBM.  The GEMMs are plain library GEMMs (weight streaming) - the
-hand-written part is everything between them.  No CPU fallback: construction fails without the
-HIP extension or without a GPU.
+the 288 GB of HBM.  The projections of steps of <= 256 rows run on the hand-written weight-streaming
+split-K GEMM (`lade_gemm_skinny`; its fp32 partials are summed by the consumer kernels, the gate/up
+GEMM carries SwiGLU in its epilogue) wherever the per-shape autotune finds it faster than the
+library GEMM (hipBLASLt through torch.matmul); wider steps (prefill chunks), fp32 and the lm_head use
+the library.  No CPU fallback: construction fails without the HIP extension or without a GPU.
 """
 from __future__ import annotations
 
@@ -111,7 +113,10 @@ class StepEngine:
             src = weights.pop(k) if consume_weights else weights[k]
             return src.to(device=dev, dtype=dt)
 
-        tied = weights["lm_head"] is weights["embed"]
+        # tied embeddings: same storage (HF hands out a fresh tensor wrapper per `.weight.data`, so identity of the python objects
+        # says nothing)
+        lm, em = weights["lm_head"], weights["embed"]
+        tied = lm is em or (lm.shape == em.shape and lm.dtype == em.dtype and lm.device == em.device and lm.data_ptr() == em.data_ptr())
         self.embed = W("embed").contiguous()
         self.norm_w = W("norm").contiguous()
         self.lm_head = self.embed if tied else W("lm_head").contiguous()
@@ -233,7 +238,10 @@ class StepEngine:
         N, K = ws[0].shape
         # one decision per (shape, row class, dtype) and process: engines of the same model (lookahead-parallel ranks run as
         # threads, a decoder rebuilt on the same weights) must pick the same kernel, or their 16-bit results round differently
-        gkey = (int(N), int(K), mclass, str(self.dtype))
+        # (the gate/up decision differs from a plain projection of the same shape - SwiGLU tail cost, fused-epilogue variant - and
+        # timings taken on one GPU model do not transfer to another)
+        gkey = (int(N), int(K), mclass, str(self.dtype), name == "wgu", self.gu_layout if name == "wgu" else 0,
+                torch.cuda.get_device_name(self.device), self.n_cu)
         with _TUNE_LOCK:
             if gkey in _TUNE_CACHE:
                 self.gemm_cfg[key] = _TUNE_CACHE[gkey]
@@ -262,7 +270,7 @@ class StepEngine:
             for bn in bns:
                 nblk = (N + bn - 1) // bn
                 for S in sorted({max(1, round(self.n_cu / nblk)), max(1, round(self.n_cu * 2 / nblk)), max(1, round(self.n_cu * 3 / nblk))}):
-                    if 2 <= S <= 16 and K // 64 >= 2 * S and S * a.shape[0] <= 16 * 128:       # the partial workspace holds 16 x 128 rows
+                    if 2 <= S <= 16 and K // 64 >= 2 * S and S * mclass <= 16 * 128:       # the partial workspace holds 16 x 128 rows (of the CLASS maximum)
                         cands.append((mb, bn, S, mt, nt))
 
         def time_it(fn, reps=16):

@@ -52,8 +52,10 @@ def config_from_hf(model) -> dict:
     theta, scaling = _rope_params(c)
     if scaling is not None:
         kind = scaling.get("rope_type", scaling.get("type"))
-        if kind not in ("linear", "dynamic", "llama3"):
-            raise cabi.LadeHipError(f"rope_scaling type {kind!r} is not implemented by the HIP step (default, linear, dynamic, llama3 are)")
+        if kind not in ("linear", "llama3"):
+            # 'dynamic' (LlamaDynamicNTKScalingRotaryEmbedding, lade/models/modeling_llama.py:292-318) rebuilds its tables as the
+            # sequence grows; it is refused here rather than approximated
+            raise cabi.LadeHipError(f"rope_scaling type {kind!r} is not implemented by the HIP step (default, linear and llama3 are)")
     if getattr(c, "attention_bias", False) or getattr(c, "mlp_bias", False):
         raise cabi.LadeHipError("projection biases are not supported (Llama-2 has none)")
     if getattr(c, "pretraining_tp", 1) not in (None, 1):
@@ -248,14 +250,16 @@ def _run(self, input_ids, do_sample, warp, stopping_criteria, eos_token_id, gene
     gs = N - 1
     need_T = max((N - 1) * (W + G) + gs, 64)
     eng = get_engine(self, max_length + need_T + W + N + 64, need_T)
-    key = (W, N, G, bool(CONFIG_MAP.get("POOL_FROM_PROMPT", 0)), R)
+    key = (W, N, G, bool(CONFIG_MAP.get("POOL_FROM_PROMPT", 0)), R, bool(CONFIG_MAP.get("FORCE_LP", 0)))
     dec = getattr(self, "_lade_decoder", None)
     if dec is None or getattr(dec, "_key", None) != key or dec.e is not eng:
         lp = None
-        if R > 1:
+        force_lp = bool(CONFIG_MAP.get("FORCE_LP", 0))       # one rank on the lookahead-parallel path (its collective is a 1-rank RCCL all-gather)
+        if R > 1 or force_lp:
             from .parallel import LPContext
-            lp = LPContext(rank=CONFIG_MAP.get("LOCAL_RANK", 0), world=R)
-        dec = LookaheadDecoder(eng, W, N, G, pool_from_prompt=key[3], lp=lp, use_graph=bool(int(os.environ.get("LADE_GRAPH", "1"))) and R == 1)
+            lp = LPContext(rank=CONFIG_MAP.get("LOCAL_RANK", 0), world=R, force=force_lp)
+        # under lookahead parallelism the rank-local part of a steady step replays as a hipGraph segment (parallel.HipLPBackend)
+        dec = LookaheadDecoder(eng, W, N, G, pool_from_prompt=key[3], lp=lp, use_graph=bool(int(os.environ.get("LADE_GRAPH", "1"))))
         dec._key = key
         self._lade_decoder = dec
     # per-step output like the reference: decoded text printed incrementally under CHAT=1 (lade/decoding.py:1179-1195),

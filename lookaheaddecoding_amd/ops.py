@@ -264,6 +264,8 @@ def gemm_parts(a: torch.Tensor, w: torch.Tensor, part: torch.Tensor, n_split: in
     `*_parts` consumer kernel - no reduce pass."""
     M, K = a.shape
     N = w.shape[0]
+    if n_split * M * N > part.numel():
+        raise cabi.LadeHipError(f"split-K workspace too small: {n_split} x {M} x {N} fp32 partials > {part.numel()}")
     call("lade_gemm_skinny", ptr(a), a.stride(0), ptr(w), w.stride(0), None, 0, ptr(part), M, N, K, n_split, bn, mb, mt, nt, 0, dtype_code(a))
 
 

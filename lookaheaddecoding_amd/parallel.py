@@ -35,6 +35,7 @@ class LPContext:
     rank: int
     world: int
     group: Optional[object] = None
+    force: bool = False        # run the lookahead-parallel code path even with one rank (a 1-GPU box exercising the RCCL path)
 
     @property
     def R(self) -> int:
@@ -67,10 +68,39 @@ def rec_words(gs: int, wcap: int, G: int = 0) -> int:
     return REC_HEAD + wcap + max(G, 0) * gs
 
 
+class FileChannel:
+    """A byte channel between the ranks of one node that needs nothing but a shared directory: rank 0 publishes a blob under a
+    name (written to a temporary file, then renamed: readers never see a partial blob), the others poll for it.  What a caller
+    without torch.distributed hands to `RcclComm` for the 128-byte unique id (the reference's channel is the TCP store behind
+    `dist.init_process_group`, lade/utils.py:31)."""
+
+    def __init__(self, directory: str, rank: int, timeout_s: float = 120.0):
+        self.dir, self.rank, self.timeout_s = directory, rank, timeout_s
+        os.makedirs(directory, exist_ok=True)
+
+    def __call__(self, blob: Optional[bytes], name: str = "rccl_unique_id") -> bytes:
+        import time
+        path = os.path.join(self.dir, name)
+        if self.rank == 0:
+            tmp = path + f".tmp{os.getpid()}"
+            with open(tmp, "wb") as f:
+                f.write(blob)
+            os.replace(tmp, path)
+            return blob
+        t0 = time.time()
+        while not os.path.exists(path):
+            if time.time() - t0 > self.timeout_s:
+                raise TimeoutError(f"rank {self.rank}: nothing published at {path} after {self.timeout_s:.0f} s")
+            time.sleep(0.01)
+        with open(path, "rb") as f:
+            return f.read()
+
+
 class RcclComm:
-    """The C ABI's own communicator (lade_lp_comm_create / lade_lp_allgather / lade_lp_comm_destroy): what a caller without
-    torch.distributed binds.  The 128-byte unique id is produced on rank 0 and handed to the other ranks by `exchange_id`
-    (any host channel; here torch.distributed's store when a process group exists, nothing for a single rank)."""
+    """The C ABI's own communicator (lade_lp_comm_create / lade_lp_allgather / lade_lp_comm_count / lade_lp_comm_destroy): what a
+    caller without torch.distributed binds.  The 128-byte unique id is produced on rank 0 and handed to the other ranks by
+    `exchange_id`, a callable `bytes (rank 0) | None -> bytes` over any host channel the caller has (`FileChannel`, a socket, MPI).
+    Only when none is given AND torch.distributed is already initialised is its store used; a world of one rank needs no channel."""
 
     def __init__(self, rank: int, world: int, exchange_id=None):
         import ctypes as C
@@ -82,14 +112,27 @@ class RcclComm:
         ident = bytes(buf)
         if world > 1:
             if exchange_id is None:
+                if not (dist.is_available() and dist.is_initialized()):
+                    raise cabi.LadeHipError("RcclComm with world > 1 needs `exchange_id` (a byte channel for the 128-byte RCCL unique id, e.g. "
+                                            "parallel.FileChannel) when torch.distributed is not initialised")
+
                 def exchange_id(b):
                     box = [b if rank == 0 else None]
                     dist.broadcast_object_list(box, src=0)
                     return box[0]
-            ident = exchange_id(ident)
+            ident = exchange_id(ident if rank == 0 else None)
+            if not isinstance(ident, (bytes, bytearray)) or len(ident) != 128:
+                raise cabi.LadeHipError("exchange_id must return rank 0's 128-byte unique id on every rank")
         handle = C.c_void_p()
-        cabi.call_plain("lade_lp_comm_create", C.create_string_buffer(ident, 128), rank, world, C.byref(handle))
+        cabi.call_plain("lade_lp_comm_create", C.create_string_buffer(bytes(ident), 128), rank, world, C.byref(handle))
         self.handle = handle
+
+    def count(self) -> int:
+        """ranks the communicator spans (ncclCommCount)"""
+        import ctypes as C
+        n = C.c_int32(0)
+        self._cabi.call_plain("lade_lp_comm_count", self.handle, C.byref(n))
+        return int(n.value)
 
     def all_gather(self, out: torch.Tensor, inp: torch.Tensor) -> None:
         assert out.dtype == torch.int32 and inp.dtype == torch.int32 and out.numel() == self.world * inp.numel()
@@ -99,6 +142,29 @@ class RcclComm:
         if self.handle is not None:
             self._cabi.call_plain("lade_lp_comm_destroy", self.handle)
             self.handle = None
+
+
+# ---- rank 0's GEMM autotune table as a fixed int32 block (so that it can travel through the step's own all-gather) ----
+_TUNE_FIELDS = 6           # present flag + (mb, bn, S, mt, nt)
+
+
+def encode_tune_table(table: dict, names: Sequence[str], classes: Sequence[int]) -> List[int]:
+    out: List[int] = []
+    for n in names:
+        for m in classes:
+            v = table.get(f"{n}:{m}")
+            out += [0] * _TUNE_FIELDS if v is None else [1] + [int(x) for x in v]
+    return out
+
+
+def decode_tune_table(words: Sequence[int], names: Sequence[str], classes: Sequence[int]) -> dict:
+    out, i = {}, 0
+    for n in names:
+        for m in classes:
+            w = [int(x) for x in words[i:i + _TUNE_FIELDS]]
+            out[f"{n}:{m}"] = tuple(w[1:]) if w[0] else None
+            i += _TUNE_FIELDS
+    return out
 
 
 class HipLPBackend:
@@ -248,15 +314,28 @@ class HipLPBackend:
         return t.tolist()
 
     def sync_gemm_choice(self, lp: LPContext) -> None:
-        """Once per process group: rank 0's autotuned GEMM table is adopted by every rank (each process would otherwise time
-        its own candidates and could settle on kernels that round 16-bit results differently)."""
+        """Once per engine: rank 0's autotuned GEMM table is adopted by every rank (each process would otherwise time its own
+        candidates and could settle on kernels that round 16-bit results differently).  With the C ABI's communicator the table
+        travels as a fixed int32 block through the same all-gather the step uses - no torch.distributed needed; otherwise through
+        the process group's object broadcast.  A world of more than one rank with neither is refused rather than left to race."""
         e = self.dec.e
-        if getattr(e, "_lp_gemm_synced", False) or not e.custom_gemm or not (dist.is_available() and dist.is_initialized()):
+        if getattr(e, "_lp_gemm_synced", False) or not e.custom_gemm or lp.R == 1:
             return
-        box = [e.tune_all() if lp.rank == 0 else None]
-        dist.broadcast_object_list(box, src=0, group=lp.group)
-        if lp.rank != 0:
-            e.adopt_gemm_cfg(box[0])
+        if self.comm is not None:
+            words = encode_tune_table(e.tune_all() if lp.rank == 0 else {}, e.GEMM_NAMES, e.ROW_CLASSES)
+            mine = torch.tensor(words, dtype=torch.int32, device=self.device)
+            allw = torch.zeros(lp.R * mine.numel(), dtype=torch.int32, device=self.device)
+            self.comm.all_gather(allw, mine)
+            if lp.rank != 0:
+                e.adopt_gemm_cfg(decode_tune_table(allw[:mine.numel()].tolist(), e.GEMM_NAMES, e.ROW_CLASSES))
+        elif dist.is_available() and dist.is_initialized():
+            box = [e.tune_all() if lp.rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=lp.group)
+            if lp.rank != 0:
+                e.adopt_gemm_cfg(box[0])
+        else:
+            raise self.dec_error("lookahead parallelism with more than one rank needs a channel for rank 0's GEMM table: the C ABI "
+                                 "communicator (LADE_LP_COLLECTIVE=abi / LPRunner(comm=...)) or an initialised torch.distributed group")
         e._lp_gemm_synced = True
 
 
@@ -264,9 +343,12 @@ class LPRunner:
     """Stepwise driver of greedy lookahead decoding under lookahead parallelism (start / step), used by
     `greedy_lp` and by bench.py.  `dec` supplies W, N, G and the LPContext; `backend` defaults to the HIP backend."""
 
-    def __init__(self, dec, backend=None, all_gather=None):
+    def __init__(self, dec, backend=None, all_gather=None, comm: Optional[RcclComm] = None):
         self.dec = dec
         self.lp: LPContext = dec.lp
+        if comm is not None:                 # a communicator the caller built over its own channel (no torch.distributed involved)
+            self.comm = comm
+            all_gather = comm.all_gather
         # the collective is injectable so that tests can run several ranks inside one process.  Default: torch.distributed's
         # all_gather_into_tensor (RCCL); LADE_LP_COLLECTIVE=abi routes it through the C ABI's own communicator
         # (lade_lp_allgather) instead - the path a caller without torch.distributed uses.

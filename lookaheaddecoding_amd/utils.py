@@ -42,6 +42,8 @@ def _join_lookahead_parallel_group(workers: int, backend: str) -> None:
             dist.init_process_group(backend, rank=rank, device_id=torch.device("cuda", rank))
         else:
             dist.init_process_group(backend, rank=rank)
+            if torch.cuda.is_available() and rank < torch.cuda.device_count():
+                torch.cuda.set_device(rank)          # the reference binds rank r to GPU r whatever the backend (lade/utils.py:31)
     assert dist.get_world_size() == workers, "DIST_WORKERS config should be equal to work size"
 
 
