@@ -470,6 +470,7 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     wg_barrier();
+    dbg_stamp(a, 7);
     constexpr int RS = 2 * D + 16;                     // staging row stride (bytes), 16-B aligned
     // staging rows of row group rg: the merge slot of (kq = 1, rg), which only wave (rg, 0) reads (LDS operations of one wave
     // execute in order, so its staging writes cannot overtake its own merge reads); without key parts to merge, the ring head

@@ -49,7 +49,7 @@ def main():
                     br = ops.attn_block_rows(a.H // a.Hkv, T) if not os.environ.get('LADE_ATTN_SHAPE') else int(os.environ['LADE_ATTN_SHAPE'])
                     nwg = a.Hkv * n * ((T * (a.H // a.Hkv) + br - 1) // br)
                     tl = tl[:nwg].double()
-                    rel = tl[:, 1:7] - tl[:, :1]
+                    rel = tl[:, 1:8] - tl[:, :1]          # stamps 1..7 (7 = key-part states published, before the merge reads)
                     order = torch.argsort(tl[:, 0])
                     half = len(order) // 2
                     for nm, idx in (("first-started half", order[:half]), ("second half", order[half:])):
