@@ -43,11 +43,44 @@ struct AttnK {
     float* part_ml;       // [n_splits][H][T][2] (running max in log2 units, running sum)
     const int32_t* dyn_P;
     int64_t q_row_stride, out_row_stride;
-    int H, Hkv, S_max, n_splits;
+    int H, Hkv, S_max, n_splits, n_rep;
     float scale_log2;   // scale * log2(e)
     int dbg;
+    // work-group -> (row block, KV head, split) decode of the 1-D grid (see block_decode): magic multipliers for / n_splits and / Hkv
+    uint32_t ns_magic, hkv_magic;
+    int n_groups;       // row blocks x KV heads
+    // in-launch split merge (lade_attn_args.merge_ws): arrival word per (row block, KV head) group, error word behind them
+    unsigned long long* merge_ctr;
+    uint32_t* merge_err;
     lade_mask_params m;
 };
+
+// ---- 1-D grid, XCD aware ---------------------------------------------------------------------------------------------------------
+// Consecutive work-group ids are dealt round-robin to the chip's 8 XCDs (each with its own L2).  Block b = x + 8 (q n_splits + sp) is
+// split sp of group g = x + 8 q, group = (row block rb, KV head kvh) with g = rb Hkv + kvh: every split of a group - and, when Hkv is a
+// multiple of 8 (Llama-2-70B: 8), every row block of a KV head - has the same b mod 8.  That placement is what lets (a) the row blocks of
+// one GQA head share one L2 copy of its K / V stream and (b) the splits of a group merge INSIDE the launch through that L2.
+__device__ __forceinline__ uint32_t div_magic(uint32_t x, uint32_t magic) { return magic ? __umulhi(x, magic) : x; }     // magic 0: divisor 1
+
+struct BlockId { int rb, kvh, sp, group; bool live; };
+__device__ __forceinline__ BlockId block_decode(const AttnK& a) {
+    const uint32_t b = blockIdx.x;
+    const uint32_t x = b & 7u, j = b >> 3;
+    const uint32_t q = div_magic(j, a.ns_magic);
+    BlockId r;
+    r.sp = (int)(j - q * (uint32_t)a.n_splits);
+    r.group = (int)(x + 8u * q);
+    r.rb = (int)div_magic((uint32_t)r.group, a.hkv_magic);
+    r.kvh = r.group - r.rb * a.Hkv;
+    r.live = r.group < a.n_groups;
+    return r;
+}
+
+__device__ __forceinline__ uint32_t xcc_id() {
+    uint32_t v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 7u;
+}
 
 // ---- mask predicate --------------------------------------------------------------------
 // Row descriptor derived once per lane from the closed form.
@@ -159,6 +192,79 @@ template <> struct Mfma<F16> {
     }
 };
 
+// ---- merge of split-KV partials (shared by the in-launch merge and lade_attn_combine: identical arithmetic, identical results) ----
+// out = sum_s w_s o_s / sum_s w_s with w_s = l_s 2^(m_s - m); o_s = normalised per-split outputs in the model dtype.  One call merges
+// 16 bytes (8 values) of one (token, head); splits are taken 8 at a time and ALL loads of a group are requested before the first use.
+// LD: loader with  float2 ml(int split)  and  u32x4 po(int split).
+template <typename T, typename LD>
+__device__ __forceinline__ u32x4 merge_splits(int ns, LD ld) {
+    float mx = NEG_BIG, wsum = 0.f;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < ns; s0 += 8) {
+        float2 v[8];
+        u32x4 o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int sidx = min(s0 + j, ns - 1);
+            v[j] = ld.ml(sidx);
+            o[j] = ld.po(sidx);
+        }
+        // pin the (m, l) loads here: left alone, the compiler sinks each of them into the `s0 + j < ns` branch that first uses it,
+        // one dependent memory latency after the other (five in a row at 8 splits)
+        __builtin_amdgcn_sched_barrier(0);               // ... and keep all sixteen loads in front of the first wait
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(v[j].x), "+v"(v[j].y));
+        float gm = mx;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (s0 + j < ns && v[j].y > 0.f) gm = fmaxf(gm, v[j].x);
+        const float resc = __builtin_amdgcn_exp2f(mx - gm);      // 2^(NEG_BIG - gm) = 0 on the first group
+        mx = gm;
+        wsum *= resc;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] *= resc;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float ws = (s0 + j < ns && v[j].y > 0.f) ? v[j].y * __builtin_amdgcn_exp2f(v[j].x - mx) : 0.f;
+            wsum += ws;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[2 * e] += ws * to_f32<T>((uint16_t)(o[j][e] & 0xffffu));
+                acc[2 * e + 1] += ws * to_f32<T>((uint16_t)(o[j][e] >> 16));
+            }
+        }
+    }
+    const float inv = wsum > 0.f ? 1.f / wsum : 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] *= inv;
+    u32x4 wv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wv[e] = pack2<T>(acc[2 * e], acc[2 * e + 1]);
+    return wv;
+}
+
+// plain loads (a separate launch: the partials were written by an earlier kernel)
+struct PlainPartials {
+    const float* ml_p; size_t ml_stride;           // floats
+    const uint16_t* po_p; size_t po_stride;        // elements
+    __device__ __forceinline__ float2 ml(int s) const { return *reinterpret_cast<const float2*>(ml_p + s * ml_stride); }
+    __device__ __forceinline__ u32x4 po(int s) const { return *reinterpret_cast<const u32x4*>(po_p + s * po_stride); }
+};
+
+// L1-bypassing loads (sc1): the partials were written DURING this launch by other work-groups of the same XCD, they sit in its L2;
+// this CU's L1 may still hold the lines an earlier launch (the previous layer) left in the same buffers
+struct L2Partials {
+    __amdgpu_buffer_rsrc_t ml_rsrc, po_rsrc;
+    uint32_t ml_off, ml_stride, po_off, po_stride;      // bytes
+    __device__ __forceinline__ float2 ml(int s) const {
+        const u32x2 r = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(ml_rsrc, ml_off + (uint32_t)s * ml_stride, 0, 16));
+        return float2{__uint_as_float(r[0]), __uint_as_float(r[1])};
+    }
+    __device__ __forceinline__ u32x4 po(int s) const {
+        return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(po_rsrc, po_off + (uint32_t)s * po_stride, 0, 16));
+    }
+};
+
 constexpr float RESCALE_THR = 8.0f;    // log2 units: the running max is only raised when it grows by more
 
 // optional in-kernel timeline (build with -DLADE_ATTN_TIMELINE, run with LADE_ATTN_DBG=16): thread 0 of every
@@ -167,7 +273,7 @@ constexpr float RESCALE_THR = 8.0f;    // log2 units: the running max is only ra
 __device__ __forceinline__ void dbg_stamp(const AttnK& a, int slot) {
     if ((a.dbg & 16) && threadIdx.x == 0) {
         const size_t base = (size_t)a.n_splits * a.H * a.m.T * 2;
-        const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const int wg = blockIdx.x;
         unsigned long long tnow = __builtin_readcyclecounter();
         reinterpret_cast<unsigned long long*>(a.part_ml + base)[(size_t)wg * 8 + slot] = tnow;
     }
@@ -226,8 +332,10 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
     else { rg = 0; kq = wave; }
     const int ts_mine = kq >> 1, kh = kq & 1;      // this wave's tile within the stage, and its 32-key half of that tile
     const int ql = lane & 31, hi = lane >> 5;
-    const int kvh = blockIdx.y, sp = blockIdx.z;
-    const int n_rep = a.H / a.Hkv;
+    const BlockId bid = block_decode(a);
+    if (!bid.live) return;                          // padding of the grid to a multiple of 8 groups
+    const int kvh = bid.kvh, sp = bid.sp, rbk = bid.rb;
+    const int n_rep = a.n_rep;
     const int ns = a.n_splits;
 
     const uint16_t* kbase = a.k + (size_t)kvh * a.S_max * D;
@@ -241,7 +349,7 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
     if (m.is_prefill) {
         // plain causal rows (prefill chunks, modeling_llama.py:124-130): no row of this block sees a key beyond its last token, so
         // the tiles behind it are neither requested nor computed - the splits of the block partition only what it can see
-        const int r0 = blockIdx.x * ROWS, r1 = min(r0 + ROWS, n_rep * m.T) - 1;
+        const int r0 = rbk * ROWS, r1 = min(r0 + ROWS, n_rep * m.T) - 1;
         const int hg0 = r0 / m.T, hg1 = r1 / m.T;
         const int tmax = hg0 != hg1 ? m.T - 1 : r1 - hg1 * m.T;
         n_tiles = min(n_tiles, (m.P + tmax + 1 + KT - 1) / KT);
@@ -297,7 +405,7 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
         const int piece = wave * QPW + i;
         const int row = piece * (64 / K_CPR) + lane / K_CPR;
         const int c = (lane % K_CPR) ^ swz16<2 * D>(row);
-        int r = blockIdx.x * ROWS + row, hg, t;
+        int r = rbk * ROWS + row, hg, t;
         if (r >= n_rows) r = 0;                       // rows past the end read row 0; never stored
         split_row(r, hg, t);
         const uint16_t* src = a.q + (size_t)t * a.q_row_stride + (size_t)(kvh * n_rep + hg) * D + c * 8;
@@ -321,7 +429,7 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
     };
 
     // this lane's query row (overlaps the DMA flight)
-    const int r = blockIdx.x * ROWS + rg * 32 + ql;
+    const int r = rbk * ROWS + rg * 32 + ql;
     const bool valid = r < n_rows;
     int hg = 0, t = 0;
     if (valid) split_row(r, hg, t);
@@ -522,7 +630,7 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
     constexpr int CPR = 2 * D / 16;                    // 16-B chunks per output row
     uint16_t* obase = a.n_splits == 1 ? a.out : a.part_o + (size_t)sp * m.T * a.H * D;
     const int64_t ostride = a.n_splits == 1 ? a.out_row_stride : (int64_t)a.H * D;
-    const int row0 = blockIdx.x * ROWS;
+    const int row0 = rbk * ROWS;
     const int n_store = min(ROWS, n_rows - row0) * CPR;
     for (int idx = tid; idx < n_store; idx += NTHR) {
         const int row = idx / CPR, c = idx % CPR;
@@ -536,6 +644,50 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     dbg_stamp(a, 6);
 #endif
+    if (a.merge_ctr == nullptr || a.n_splits == 1) return;
+
+    // ---- in-launch merge of the key splits (lade_attn_args.merge_ws) --------------------------------------------------------------
+    // Every split of this (row block, KV head) group runs on ONE XCD (block_decode), so the hand-off goes through that XCD's L2 and
+    // costs ~1.3 us instead of a launch boundary plus a second kernel: plain stores, every storing wave waits for their acknowledgement
+    // (vmcnt(0): the data is in L2), ONE device-scope RMW announces the arrival, and the last arriver re-reads all partials with
+    // L1-bypassing (sc1) loads and writes the merged rows.  The arrival word carries an 8-bit count and eight 7-bit per-XCD counts: the
+    // last arriver also learns WHERE the others ran; a split that ran elsewhere is reported through merge_err (its plain stores may still
+    // sit in another L2) - the host turns that into an error, never into tokens (engine.check_health).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wg_barrier();                                   // staging rows no longer read: LDS word 0 is free
+    uint32_t* last_flag = reinterpret_cast<uint32_t*>(smem);
+    if (tid == 0) {
+        const uint32_t me = xcc_id();
+        const unsigned long long add = 1ull | (1ull << (8 + 7 * me));
+        const unsigned long long tot = __hip_atomic_fetch_add(a.merge_ctr + bid.group, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
+        const bool last = (int)(tot & 0xffull) == a.n_splits;
+        if (last) {
+            if ((int)((tot >> (8 + 7 * me)) & 0x7full) != a.n_splits) atomicOr(a.merge_err, 1u);
+            // back to zero through the same path the arrivals took (an RMW), ready for the next launch
+            (void)__hip_atomic_fetch_add(a.merge_ctr + bid.group, 0ull - tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        *last_flag = last ? 1u : 0u;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wg_barrier();
+    if (*last_flag == 0u) return;
+    {
+        L2Partials ld;
+        ld.ml_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.part_ml, 0, 0xffffffff, 0x00020000);
+        ld.po_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.part_o, 0, 0xffffffff, 0x00020000);
+        ld.ml_stride = (uint32_t)a.H * (uint32_t)m.T * 8u;
+        ld.po_stride = (uint32_t)m.T * (uint32_t)a.H * (uint32_t)(2 * D);
+        for (int idx = tid; idx < n_store; idx += NTHR) {
+            const int row = idx / CPR, c = idx % CPR;
+            int hg2, t2;
+            split_row(row0 + row, hg2, t2);
+            const int qh2 = kvh * n_rep + hg2;
+            ld.ml_off = ((uint32_t)qh2 * (uint32_t)m.T + (uint32_t)t2) * 8u;
+            ld.po_off = (((uint32_t)t2 * (uint32_t)a.H + (uint32_t)qh2) * (uint32_t)D + (uint32_t)c * 8u) * 2u;
+            const u32x4 wv = merge_splits<T>(a.n_splits, ld);
+            *reinterpret_cast<u32x4*>(a.out + (size_t)t2 * a.out_row_stride + (size_t)qh2 * D + c * 8) = wv;
+        }
+    }
 }
 
 // merges split-KV partials: out = sum_s w_s o_s / sum_s w_s with w_s = l_s 2^(m_s - m); o_s are the
@@ -545,55 +697,13 @@ template <typename T>
 __global__ __launch_bounds__(256) void attn_combine_kernel(AttnK a, int D) {
     const int t = blockIdx.x, qh = blockIdx.y * blockDim.y + threadIdx.y;
     const int Tn = a.m.T;
-    const int ns = a.n_splits;
     const int d0 = threadIdx.x * 8;
-    const float* ml = a.part_ml + ((size_t)qh * Tn + t) * 2;
-    const size_t ml_stride = (size_t)a.H * Tn * 2;
-    const uint16_t* po = a.part_o + ((size_t)t * a.H + qh) * D + d0;
-    const size_t po_stride = (size_t)Tn * a.H * D;
-    // one pass, 8 splits at a time: all (m, l) and partial-output loads of a group are issued together
-    float mx = NEG_BIG, wsum = 0.f;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int s0 = 0; s0 < ns; s0 += 8) {
-        float2 v[8];
-        u32x4 o[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int s = min(s0 + j, ns - 1);
-            v[j] = *reinterpret_cast<const float2*>(ml + s * ml_stride);
-            o[j] = *reinterpret_cast<const u32x4*>(po + s * po_stride);
-        }
-        // pin the (m, l) loads here: left alone, the compiler sinks each of them into the `s0 + j < ns` branch that first uses it,
-        // one dependent memory latency after the other (five in a row at 8 splits)
-        __builtin_amdgcn_sched_barrier(0);               // ... and keep all sixteen loads in front of the first wait
-#pragma unroll
-        for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(v[j].x), "+v"(v[j].y));
-        float gm = mx;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (s0 + j < ns && v[j].y > 0.f) gm = fmaxf(gm, v[j].x);
-        const float resc = __builtin_amdgcn_exp2f(mx - gm);      // 2^(NEG_BIG - gm) = 0 on the first group
-        mx = gm;
-        wsum *= resc;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] *= resc;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float ws = (s0 + j < ns && v[j].y > 0.f) ? v[j].y * __builtin_amdgcn_exp2f(v[j].x - mx) : 0.f;
-            wsum += ws;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[2 * e] += ws * to_f32<T>((uint16_t)(o[j][e] & 0xffffu));
-                acc[2 * e + 1] += ws * to_f32<T>((uint16_t)(o[j][e] >> 16));
-            }
-        }
-    }
-    const float inv = wsum > 0.f ? 1.f / wsum : 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] *= inv;
-    u32x4 wv;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) wv[e] = pack2<T>(acc[2 * e], acc[2 * e + 1]);
+    PlainPartials ld;
+    ld.ml_p = a.part_ml + ((size_t)qh * Tn + t) * 2;
+    ld.ml_stride = (size_t)a.H * Tn * 2;
+    ld.po_p = a.part_o + ((size_t)t * a.H + qh) * D + d0;
+    ld.po_stride = (size_t)Tn * a.H * D;
+    const u32x4 wv = merge_splits<T>(a.n_splits, ld);
     *reinterpret_cast<u32x4*>(a.out + (size_t)t * a.out_row_stride + (size_t)qh * D + d0) = wv;
 }
 
@@ -675,12 +785,19 @@ static int validate(const lade_attn_args* a) {
     return LADE_OK;
 }
 
+// floor(x / d) == umulhi(x, magic_for(d)) for x * d < 2^32 (d = 1: magic 0, see div_magic)
+static uint32_t magic_for(int d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d); }
+
 static AttnK make_k(const lade_attn_args* a) {
     AttnK k;
     k.q = (const uint16_t*)a->q; k.k = (const uint16_t*)a->k_cache; k.vt = (const uint16_t*)a->vt_cache;
     k.out = (uint16_t*)a->out; k.part_o = (uint16_t*)a->part_o; k.part_ml = a->part_ml; k.dyn_P = a->dyn_P;
     k.q_row_stride = a->q_row_stride; k.out_row_stride = a->out_row_stride;
-    k.H = a->H; k.Hkv = a->Hkv; k.S_max = a->S_max; k.n_splits = a->n_splits;
+    k.H = a->H; k.Hkv = a->Hkv; k.S_max = a->S_max; k.n_splits = a->n_splits; k.n_rep = a->H / a->Hkv;
+    k.ns_magic = magic_for(a->n_splits); k.hkv_magic = magic_for(a->Hkv);
+    k.n_groups = 0;                                 // set per work-group shape (launch_fwd_shape)
+    k.merge_ctr = (unsigned long long*)a->merge_ws;
+    k.merge_err = a->merge_ws ? (uint32_t*)((unsigned long long*)a->merge_ws + LADE_ATTN_MERGE_GROUPS) : nullptr;
     k.scale_log2 = a->scale * 1.4426950408889634f;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("LADE_ATTN_DBG"); dbg = e ? atoi(e) : 0; } k.dbg = dbg; }
     k.m = a->mask;
@@ -689,10 +806,13 @@ static AttnK make_k(const lade_attn_args* a) {
 
 template <typename T, int D, int RG, int KQ>
 static int launch_fwd_shape(const lade_attn_args* a, hipStream_t st) {
-    const AttnK k = make_k(a);
+    AttnK k = make_k(a);
     const int n_rep = a->H / a->Hkv;
     constexpr int ROWS = 32 * RG, TPS = KQ / 2, NSTG = TPS == 1 ? 3 : 2;
-    dim3 grid(cdiv(n_rep * a->mask.T, ROWS), a->Hkv, a->n_splits);
+    k.n_groups = cdiv(n_rep * a->mask.T, ROWS) * a->Hkv;
+    LADE_REQUIRE(!k.merge_ctr || a->n_splits == 1 || k.n_groups <= LADE_ATTN_MERGE_GROUPS, LADE_E_LIMIT,
+                 "lade_attn_fwd: %d (row block, KV head) groups exceed the merge workspace (%d)", k.n_groups, LADE_ATTN_MERGE_GROUPS);
+    dim3 grid(8 * cdiv(k.n_groups, 8) * a->n_splits);       // block_decode: b = x + 8 (q n_splits + sp), group = x + 8 q
     const size_t lds = (size_t)KT * D * 2 * 2 * TPS * NSTG + (size_t)ROWS * D * 2;
     static bool attr_set = false;          // > 64 KiB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set) {
@@ -750,6 +870,7 @@ extern "C" int lade_attn_combine(const lade_attn_args* a, void* stream) {
     int rc = validate(a);
     if (rc) return rc;
     LADE_REQUIRE(a->n_splits > 1, LADE_E_ARG, "lade_attn_combine: n_splits=%d", a->n_splits);
+    LADE_REQUIRE(a->merge_ws == nullptr, LADE_E_ARG, "lade_attn_combine: lade_attn_fwd already merged the splits in its own launch (merge_ws is set)");
     LADE_REQUIRE(a->dtype == LADE_BF16 || a->dtype == LADE_F16, LADE_E_DTYPE, "lade_attn_combine: dtype=%d", a->dtype);
     const AttnK k = make_k(a);
     LADE_REQUIRE(a->n_splits <= 32, LADE_E_LIMIT, "lade_attn_combine: n_splits=%d > 32", a->n_splits);
