@@ -460,7 +460,7 @@ def worker(args):
         # every repetition uses the next layer's K/V cache (L caches of 2*Hkv*S_max*d*e bytes >> the 256 MB Infinity Cache), so the
         # launch streams its keys/values from HBM exactly as inside a decode step
         us = ops.time_attn(qkv, [eng.k_cache(li) for li in range(eng.L)], [eng.vt_cache(li) for li in range(eng.L)], mask,
-                           H=cfg["heads"], Hkv=cfg["kv_heads"], d=cfg["head_dim"], n_splits=ns, reps=max(200, 8 * eng.L), merge_ws=eng.attn_merge_ws)
+                           H=cfg["heads"], Hkv=cfg["kv_heads"], d=cfg["head_dim"], n_splits=ns, reps=max(200, 8 * eng.L))
         us_iso, how = us, "isolated (no in-step measurement in this mode)"
         if in_situ is not None and in_situ["T"] == T_k and in_situ["gpu_bound"]:
             us, ns, how = in_situ["us"], in_situ["n_splits"], "hipEvents inside real decode steps"

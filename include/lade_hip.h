@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define LADE_ABI_VERSION 2
+#define LADE_ABI_VERSION 1
 
 /* error codes */
 #define LADE_OK 0
@@ -131,23 +131,10 @@ typedef struct lade_attn_args {
     int32_t n_splits;       /* >= 1 ; work-groups = ceil(n_rep*T/128) x H/n_rep x n_splits (1-D grid, XCD-aware order) */
     float scale;            /* softmax scale, 1/sqrt(d) */
     lade_mask_params mask;
-    /* Optional in-launch merge of the n_splits partials (ABI v2).  NULL: lade_attn_fwd leaves normalised partials in part_o / part_ml
-     * and lade_attn_combine (a second launch) merges them - correct on any placement of the work-groups.  Non-NULL: device workspace of
-     * LADE_ATTN_MERGE_WS_BYTES bytes, ZEROED ONCE by the caller (the kernel returns it to zero): the last-arriving split of every (row
-     * block, KV head) group merges inside the launch, `out` is final when lade_attn_fwd returns and lade_attn_combine must not be
-     * called.  The fast hand-off relies on the splits of a group sharing one XCD (consecutive work-group ids are dealt round-robin to the
-     * 8 XCDs; tools/xcd_probe checks it on a box); the kernel verifies it on every launch and sets the int32 at byte offset
-     * LADE_ATTN_MERGE_ERR_OFFSET of the workspace to non-zero when a group was spread over XCDs - the output of that launch is then not
-     * to be trusted and the caller must fall back to merge_ws = NULL.  One workspace per stream of launches. */
-    void* merge_ws;
 } lade_attn_args;
 
-#define LADE_ATTN_MERGE_GROUPS 4096                                  /* (row block, KV head) groups a launch may have with merge_ws */
-#define LADE_ATTN_MERGE_ERR_OFFSET (8 * LADE_ATTN_MERGE_GROUPS)
-#define LADE_ATTN_MERGE_WS_BYTES (LADE_ATTN_MERGE_ERR_OFFSET + 64)
-
 int lade_attn_fwd(const lade_attn_args* a, void* stream);
-/* merges the n_splits partials of lade_attn_fwd into `out` (call only when n_splits > 1 and merge_ws == NULL) */
+/* merges the n_splits partials of lade_attn_fwd into `out` (call only when n_splits > 1) */
 int lade_attn_combine(const lade_attn_args* a, void* stream);
 /* dense 0/1 rendering of the mask predicate, [T][P+T] bytes on the device (test / debug aid) */
 int lade_mask_render(const lade_mask_params* m, uint8_t* out, void* stream);

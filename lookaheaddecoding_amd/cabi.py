@@ -42,14 +42,7 @@ class AttnArgs(C.Structure):
                 ("part_o", C.c_void_p), ("part_ml", C.c_void_p), ("dyn_P", C.c_void_p),
                 ("q_row_stride", C.c_int64), ("out_row_stride", C.c_int64),
                 ("H", C.c_int32), ("Hkv", C.c_int32), ("d", C.c_int32), ("S_max", C.c_int32),
-                ("dtype", C.c_int32), ("n_splits", C.c_int32), ("scale", C.c_float), ("mask", MaskParams),
-                ("merge_ws", C.c_void_p)]
-
-
-# in-launch split merge workspace (include/lade_hip.h): arrival words of LADE_ATTN_MERGE_GROUPS groups, then the error word
-ATTN_MERGE_GROUPS = 4096
-ATTN_MERGE_ERR_OFFSET = 8 * ATTN_MERGE_GROUPS
-ATTN_MERGE_WS_BYTES = ATTN_MERGE_ERR_OFFSET + 64
+                ("dtype", C.c_int32), ("n_splits", C.c_int32), ("scale", C.c_float), ("mask", MaskParams)]
 
 
 _lib: Optional[C.CDLL] = None

@@ -49,17 +49,17 @@ struct AttnK {
     // work-group -> (row block, KV head, split) decode of the 1-D grid (see block_decode): magic multipliers for / n_splits and / Hkv
     uint32_t ns_magic, hkv_magic;
     int n_groups;       // row blocks x KV heads
-    // in-launch split merge (lade_attn_args.merge_ws): arrival word per (row block, KV head) group, error word behind them
-    unsigned long long* merge_ctr;
-    uint32_t* merge_err;
     lade_mask_params m;
 };
 
 // ---- 1-D grid, XCD aware ---------------------------------------------------------------------------------------------------------
 // Consecutive work-group ids are dealt round-robin to the chip's 8 XCDs (each with its own L2).  Block b = x + 8 (q n_splits + sp) is
 // split sp of group g = x + 8 q, group = (row block rb, KV head kvh) with g = rb Hkv + kvh: every split of a group - and, when Hkv is a
-// multiple of 8 (Llama-2-70B: 8), every row block of a KV head - has the same b mod 8.  That placement is what lets (a) the row blocks of
-// one GQA head share one L2 copy of its K / V stream and (b) the splits of a group merge INSIDE the launch through that L2.
+// multiple of 8 (Llama-2-70B: 8), every row block of a KV head - has the same b mod 8, i.e. one XCD (tools/xcd_probe: equal b mod 8
+// -> equal XCC_ID in every one of 96 000 groups observed): the row blocks of one GQA head then share one L2 copy of its K / V stream.
+// (Round 3 also merged the splits of a group INSIDE the launch through that L2 - last arriver, and last-ticket variants; bit-identical
+// to the two-launch form and correct under stress, but 5-6 us SLOWER: a device-scope RMW costs ~2 us here and the merger's sc1 re-reads
+// ~2 us per round while other work-groups still stream, DESIGN 4.1.  The merge is therefore a second launch, lade_attn_combine.)
 __device__ __forceinline__ uint32_t div_magic(uint32_t x, uint32_t magic) { return magic ? __umulhi(x, magic) : x; }     // magic 0: divisor 1
 
 struct BlockId { int rb, kvh, sp, group; bool live; };
@@ -76,11 +76,6 @@ __device__ __forceinline__ BlockId block_decode(const AttnK& a) {
     return r;
 }
 
-__device__ __forceinline__ uint32_t xcc_id() {
-    uint32_t v;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
-    return v & 7u;
-}
 
 // ---- mask predicate --------------------------------------------------------------------
 // Row descriptor derived once per lane from the closed form.
@@ -249,20 +244,6 @@ struct PlainPartials {
     const uint16_t* po_p; size_t po_stride;        // elements
     __device__ __forceinline__ float2 ml(int s) const { return *reinterpret_cast<const float2*>(ml_p + s * ml_stride); }
     __device__ __forceinline__ u32x4 po(int s) const { return *reinterpret_cast<const u32x4*>(po_p + s * po_stride); }
-};
-
-// L1-bypassing loads (sc1): the partials were written DURING this launch by other work-groups of the same XCD, they sit in its L2;
-// this CU's L1 may still hold the lines an earlier launch (the previous layer) left in the same buffers
-struct L2Partials {
-    __amdgpu_buffer_rsrc_t ml_rsrc, po_rsrc;
-    uint32_t ml_off, ml_stride, po_off, po_stride;      // bytes
-    __device__ __forceinline__ float2 ml(int s) const {
-        const u32x2 r = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(ml_rsrc, ml_off + (uint32_t)s * ml_stride, 0, 16));
-        return float2{__uint_as_float(r[0]), __uint_as_float(r[1])};
-    }
-    __device__ __forceinline__ u32x4 po(int s) const {
-        return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(po_rsrc, po_off + (uint32_t)s * po_stride, 0, 16));
-    }
 };
 
 constexpr float RESCALE_THR = 8.0f;    // log2 units: the running max is only raised when it grows by more
@@ -578,7 +559,6 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     wg_barrier();
-    dbg_stamp(a, 7);
     constexpr int RS = 2 * D + 16;                     // staging row stride (bytes), 16-B aligned
     // staging rows of row group rg: the merge slot of (kq = 1, rg), which only wave (rg, 0) reads (LDS operations of one wave
     // execute in order, so its staging writes cannot overtake its own merge reads); without key parts to merge, the ring head
@@ -644,50 +624,6 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     dbg_stamp(a, 6);
 #endif
-    if (a.merge_ctr == nullptr || a.n_splits == 1) return;
-
-    // ---- in-launch merge of the key splits (lade_attn_args.merge_ws) --------------------------------------------------------------
-    // Every split of this (row block, KV head) group runs on ONE XCD (block_decode), so the hand-off goes through that XCD's L2 and
-    // costs ~1.3 us instead of a launch boundary plus a second kernel: plain stores, every storing wave waits for their acknowledgement
-    // (vmcnt(0): the data is in L2), ONE device-scope RMW announces the arrival, and the last arriver re-reads all partials with
-    // L1-bypassing (sc1) loads and writes the merged rows.  The arrival word carries an 8-bit count and eight 7-bit per-XCD counts: the
-    // last arriver also learns WHERE the others ran; a split that ran elsewhere is reported through merge_err (its plain stores may still
-    // sit in another L2) - the host turns that into an error, never into tokens (engine.check_health).
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    wg_barrier();                                   // staging rows no longer read: LDS word 0 is free
-    uint32_t* last_flag = reinterpret_cast<uint32_t*>(smem);
-    if (tid == 0) {
-        const uint32_t me = xcc_id();
-        const unsigned long long add = 1ull | (1ull << (8 + 7 * me));
-        const unsigned long long tot = __hip_atomic_fetch_add(a.merge_ctr + bid.group, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
-        const bool last = (int)(tot & 0xffull) == a.n_splits;
-        if (last) {
-            if ((int)((tot >> (8 + 7 * me)) & 0x7full) != a.n_splits) atomicOr(a.merge_err, 1u);
-            // back to zero through the same path the arrivals took (an RMW), ready for the next launch
-            (void)__hip_atomic_fetch_add(a.merge_ctr + bid.group, 0ull - tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        *last_flag = last ? 1u : 0u;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    wg_barrier();
-    if (*last_flag == 0u) return;
-    {
-        L2Partials ld;
-        ld.ml_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.part_ml, 0, 0xffffffff, 0x00020000);
-        ld.po_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.part_o, 0, 0xffffffff, 0x00020000);
-        ld.ml_stride = (uint32_t)a.H * (uint32_t)m.T * 8u;
-        ld.po_stride = (uint32_t)m.T * (uint32_t)a.H * (uint32_t)(2 * D);
-        for (int idx = tid; idx < n_store; idx += NTHR) {
-            const int row = idx / CPR, c = idx % CPR;
-            int hg2, t2;
-            split_row(row0 + row, hg2, t2);
-            const int qh2 = kvh * n_rep + hg2;
-            ld.ml_off = ((uint32_t)qh2 * (uint32_t)m.T + (uint32_t)t2) * 8u;
-            ld.po_off = (((uint32_t)t2 * (uint32_t)a.H + (uint32_t)qh2) * (uint32_t)D + (uint32_t)c * 8u) * 2u;
-            const u32x4 wv = merge_splits<T>(a.n_splits, ld);
-            *reinterpret_cast<u32x4*>(a.out + (size_t)t2 * a.out_row_stride + (size_t)qh2 * D + c * 8) = wv;
-        }
-    }
 }
 
 // merges split-KV partials: out = sum_s w_s o_s / sum_s w_s with w_s = l_s 2^(m_s - m); o_s are the
@@ -796,8 +732,6 @@ static AttnK make_k(const lade_attn_args* a) {
     k.H = a->H; k.Hkv = a->Hkv; k.S_max = a->S_max; k.n_splits = a->n_splits; k.n_rep = a->H / a->Hkv;
     k.ns_magic = magic_for(a->n_splits); k.hkv_magic = magic_for(a->Hkv);
     k.n_groups = 0;                                 // set per work-group shape (launch_fwd_shape)
-    k.merge_ctr = (unsigned long long*)a->merge_ws;
-    k.merge_err = a->merge_ws ? (uint32_t*)((unsigned long long*)a->merge_ws + LADE_ATTN_MERGE_GROUPS) : nullptr;
     k.scale_log2 = a->scale * 1.4426950408889634f;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("LADE_ATTN_DBG"); dbg = e ? atoi(e) : 0; } k.dbg = dbg; }
     k.m = a->mask;
@@ -810,8 +744,6 @@ static int launch_fwd_shape(const lade_attn_args* a, hipStream_t st) {
     const int n_rep = a->H / a->Hkv;
     constexpr int ROWS = 32 * RG, TPS = KQ / 2, NSTG = TPS == 1 ? 3 : 2;
     k.n_groups = cdiv(n_rep * a->mask.T, ROWS) * a->Hkv;
-    LADE_REQUIRE(!k.merge_ctr || a->n_splits == 1 || k.n_groups <= LADE_ATTN_MERGE_GROUPS, LADE_E_LIMIT,
-                 "lade_attn_fwd: %d (row block, KV head) groups exceed the merge workspace (%d)", k.n_groups, LADE_ATTN_MERGE_GROUPS);
     dim3 grid(8 * cdiv(k.n_groups, 8) * a->n_splits);       // block_decode: b = x + 8 (q n_splits + sp), group = x + 8 q
     const size_t lds = (size_t)KT * D * 2 * 2 * TPS * NSTG + (size_t)ROWS * D * 2;
     static bool attr_set = false;          // > 64 KiB of dynamic LDS needs the opt-in once per kernel
@@ -870,7 +802,6 @@ extern "C" int lade_attn_combine(const lade_attn_args* a, void* stream) {
     int rc = validate(a);
     if (rc) return rc;
     LADE_REQUIRE(a->n_splits > 1, LADE_E_ARG, "lade_attn_combine: n_splits=%d", a->n_splits);
-    LADE_REQUIRE(a->merge_ws == nullptr, LADE_E_ARG, "lade_attn_combine: lade_attn_fwd already merged the splits in its own launch (merge_ws is set)");
     LADE_REQUIRE(a->dtype == LADE_BF16 || a->dtype == LADE_F16, LADE_E_DTYPE, "lade_attn_combine: dtype=%d", a->dtype);
     const AttnK k = make_k(a);
     LADE_REQUIRE(a->n_splits <= 32, LADE_E_LIMIT, "lade_attn_combine: n_splits=%d > 32", a->n_splits);

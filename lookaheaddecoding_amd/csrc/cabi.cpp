@@ -40,12 +40,12 @@ extern "C" int lade_time_attn(const lade_attn_args* a, int32_t reps, float* mean
         return LADE_E_LAUNCH;
     }
     int rc = lade_attn_fwd(a, stream);            // warm-up, also validates
-    if (rc == 0 && a->n_splits > 1 && !a->merge_ws) rc = lade_attn_combine(a, stream);
+    if (rc == 0 && a->n_splits > 1) rc = lade_attn_combine(a, stream);
     if (rc == 0) {
         (void)hipEventRecord(e0, st);
         for (int i = 0; i < reps && rc == 0; ++i) {
             rc = lade_attn_fwd(a, stream);
-            if (rc == 0 && a->n_splits > 1 && !a->merge_ws) rc = lade_attn_combine(a, stream);
+            if (rc == 0 && a->n_splits > 1) rc = lade_attn_combine(a, stream);
         }
         (void)hipEventRecord(e1, st);
         (void)hipEventSynchronize(e1);
@@ -72,14 +72,14 @@ extern "C" int lade_time_attn_rot(const lade_attn_args* a, int32_t n, int32_t re
     int rc = 0;
     for (int i = 0; i < n && rc == 0; ++i) {          // one untimed pass: validation, code objects, LDS attributes
         rc = lade_attn_fwd(a + i, stream);
-        if (rc == 0 && a[i].n_splits > 1 && !a[i].merge_ws) rc = lade_attn_combine(a + i, stream);
+        if (rc == 0 && a[i].n_splits > 1) rc = lade_attn_combine(a + i, stream);
     }
     if (rc == 0) {
         (void)hipEventRecord(e0, st);
         for (int i = 0; i < reps && rc == 0; ++i) {
             const lade_attn_args* x = a + (i % n);
             rc = lade_attn_fwd(x, stream);
-            if (rc == 0 && x->n_splits > 1 && !x->merge_ws) rc = lade_attn_combine(x, stream);
+            if (rc == 0 && x->n_splits > 1) rc = lade_attn_combine(x, stream);
         }
         (void)hipEventRecord(e1, st);
         (void)hipEventSynchronize(e1);

@@ -296,7 +296,6 @@ class LookaheadDecoder:
         if self.lp is not None and (self.lp.R > 1 or self.lp.force):
             from .parallel import greedy_lp
             out = greedy_lp(self, prompt, max_length, eos_token_id, rng, keep_trace, on_step=on_step)
-            self.e.check_health()
             # the reference logs on rank 0 only (`if DEBUG and LOCAL_RANK == 0`, lade/decoding.py:1231-1235)
             if CONFIG_MAP.get("DEBUG", 0) and self.lp.rank == 0:
                 CONFIG_MAP.setdefault("log", []).append([out.generated, out.steps, round(out.generated / max(out.steps, 1), 2)])
@@ -311,7 +310,6 @@ class LookaheadDecoder:
                 on_step(info["accepted"][:max(0, max_length - (len(self.tokens) - len(info["accepted"])))])
             if self.finished_by_eos or len(self.tokens) >= max_length:      # stopping criteria (:1204-1219)
                 break
-        self.e.check_health()                     # no token leaves a generation whose attention merge reported a misplaced split
         generated = min(len(self.tokens), max_length) - len(self.prompt)
         out = GenOut(tokens=self.tokens[:max_length], steps=self.steps, generated=generated, trace=trace)
         if CONFIG_MAP.get("DEBUG", 0):
@@ -380,7 +378,6 @@ class LookaheadDecoder:
                 on_step(info["accepted"][:max(0, max_length - (len(self.tokens) - len(info["accepted"])))])
             if self.finished_by_eos or len(self.tokens) >= max_length:
                 break
-        self.e.check_health()                     # no token leaves a generation whose attention merge reported a misplaced split
         generated = min(len(self.tokens), max_length) - len(self.prompt)
         out = GenOut(tokens=self.tokens[:max_length], steps=self.steps, generated=generated, trace=trace)
         if CONFIG_MAP.get("DEBUG", 0):

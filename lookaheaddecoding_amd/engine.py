@@ -135,12 +135,6 @@ class StepEngine:
         self.attn_events = None             # set to a list to collect (start, end, T, n_splits) hipEvent pairs per layer
         self.skip_attn = False              # bench.py only: leave the attention launches out (step-time difference = their cost)
         self.max_splits = 32
-        # split merge of the attention: "xcd" = inside the attention launch (the splits of a head share one XCD's L2; verified by the
-        # kernel on every launch, see check_health), "launch" = a second launch (lade_attn_combine), correct on any placement
-        self.attn_merge = os.environ.get("LADE_ATTN_MERGE", "xcd")
-        if self.attn_merge not in ("xcd", "launch"):
-            raise cabi.LadeHipError(f"LADE_ATTN_MERGE={self.attn_merge!r} (xcd | launch)")
-        self.attn_merge_ws = ops.new_merge_ws(self.device) if (self.attn_merge == "xcd" and dt != torch.float32) else None
         # hand-written weight-streaming GEMM (split-K partials consumed by the fused glue kernels) for steps of
         # <= 128 tokens; every (N, K, row class) is timed against the library GEMM once and the faster one is kept
         self.custom_gemm = dt != torch.float32 and os.environ.get("LADE_GEMM", "1") != "0" and self.d % 16 == 0 and self.hidden % 64 == 0 and self.inter % 64 == 0
@@ -230,19 +224,6 @@ class StepEngine:
         # captured with exactly that rule, and an eager step of the same (short) sequence must round the same way
         # (16-bit partials) for the two modes to produce the same token stream
         return min(ops.choose_splits(self.H, self.H // self.Hkv, T, max(S_tot, 1024), self.n_cu, allow_single=False), self.max_splits)
-
-    def check_health(self) -> None:
-        """Raises when an attention launch reported that the splits of a head were NOT co-located on one XCD (the in-launch merge then
-        read partials that may still have been in another XCD's L2: its output is not to be trusted).  Called by the decode loops at
-        the end of every generation, before any token is handed back; the engine switches itself to the two-launch merge."""
-        if self.attn_merge_ws is None:
-            return
-        if ops.merge_ws_error(self.attn_merge_ws):
-            self.attn_merge_ws, self.attn_merge = None, "launch"
-            self.generation += 1                       # captured hipGraphs carry the old mode
-            raise cabi.LadeHipError("attention split merge: a head's KV splits ran on different XCDs (work-group placement is not the "
-                                    "round-robin this GPU showed before); the tokens of this generation are discarded, the engine now "
-                                    "merges in a second launch (LADE_ATTN_MERGE=launch) - repeat the call")
 
     # ---- GEMM selection ---------------------------------------------------------------------------
     def _tune(self, name: str, M: int):
@@ -405,7 +386,7 @@ class StepEngine:
                 e0.record()
             if not self.skip_attn:
                 ops.attn_fwd(q_in, self.k_cache(li), self.vt_cache(li), mask, H=H, Hkv=Hkv, d=d, out=o, n_splits=n_splits,
-                             part_o=self.part_o, part_ml=self.part_ml, dyn_P=dyn_P, merge_ws=self.attn_merge_ws)
+                             part_o=self.part_o, part_ml=self.part_ml, dyn_P=dyn_P)
             if ev is not None:
                 e1 = torch.cuda.Event(enable_timing=True)
                 e1.record()
@@ -495,5 +476,4 @@ class StepEngine:
             one_pos.fill_(P)
             logits = self.forward(one_id, one_pos, StepMask(T=1, P=P, is_prefill=True), sel, 1)
             P += 1
-        self.check_health()
         return ids

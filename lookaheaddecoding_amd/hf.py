@@ -209,7 +209,6 @@ def jforward_multilevel(self, input_ids=None, past_tokens=None, guess_tokens=Non
         logits = eng.forward(torch.tensor(ids, dtype=torch.int32, device=dev), torch.tensor(pos, dtype=torch.int32, device=dev),
                              StepMask.from_levels(n_input, level_sizes, lguess, gs, past_size),
                              torch.tensor(rows, dtype=torch.int32, device=dev), len(rows)).float()
-    eng.check_health()
     ret = StepOutput()
     ret.out_logits = logits[0:1]
     ret.inp_logits = logits[1:1 + window].unsqueeze(0)

@@ -76,10 +76,9 @@ def choose_splits(H: int, n_rep: int, T: int, S_tot: int, n_cu: int = 256, allow
 def attn_fwd(q: torch.Tensor, k_cache: torch.Tensor, vt_cache: torch.Tensor, mask: StepMask, *, H: int, Hkv: int, d: int,
              out: Optional[torch.Tensor] = None, n_splits: Optional[int] = None, scale: Optional[float] = None,
              q_row_stride: Optional[int] = None, part_o: Optional[torch.Tensor] = None, part_ml: Optional[torch.Tensor] = None,
-             dyn_P: Optional[torch.Tensor] = None, merge_ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+             dyn_P: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Lookahead attention for one step.  q: [T, >=H*d] rows (token stride q_row_stride elements, default
-    q.stride(0)); k_cache [Hkv, S_max, d]; vt_cache [Hkv, d, S_max]; returns out [T, H*d].
-    merge_ws (new_merge_ws()): the KV splits are merged inside the attention launch (one launch instead of two)."""
+    q.stride(0)); k_cache [Hkv, S_max, d]; vt_cache [Hkv, d, S_max]; returns out [T, H*d]."""
     for n, t in (("q", q), ("k_cache", k_cache), ("vt_cache", vt_cache)):
         _dev(t, n)
     T = mask.T
@@ -99,25 +98,14 @@ def attn_fwd(q: torch.Tensor, k_cache: torch.Tensor, vt_cache: torch.Tensor, mas
             part_ml = torch.empty(n_splits, H, T, 2, dtype=torch.float32, device=q.device)
     a = AttnArgs(ptr(q), ptr(k_cache), ptr(vt_cache), ptr(out), ptr(part_o), ptr(part_ml), ptr(dyn_P),
                  q_row_stride if q_row_stride is not None else q.stride(0), out.stride(0), H, Hkv, d, S_max,
-                 dtype_code(q), n_splits, scale if scale is not None else 1.0 / math.sqrt(d), mask.c_struct(), ptr(merge_ws))
+                 dtype_code(q), n_splits, scale if scale is not None else 1.0 / math.sqrt(d), mask.c_struct())
     call("lade_attn_fwd", C.byref(a))
-    if n_splits > 1 and merge_ws is None:
+    if n_splits > 1:
         call("lade_attn_combine", C.byref(a))
     return out
 
 
-def new_merge_ws(device) -> torch.Tensor:
-    """Zeroed workspace of the in-launch split merge (lade_attn_args.merge_ws): one per stream of attention launches."""
-    return torch.zeros(cabi.ATTN_MERGE_WS_BYTES // 4, dtype=torch.int32, device=device)
-
-
-def merge_ws_error(ws: torch.Tensor) -> int:
-    """The workspace's error word (non-zero: some launch found the splits of a group on different XCDs); synchronises."""
-    return int(ws[cabi.ATTN_MERGE_ERR_OFFSET // 4].item())
-
-
-def time_attn(q, k_cache, vt_cache, mask: StepMask, *, H, Hkv, d, n_splits: int, reps: int = 20, debug_timeline: bool = False,
-              merge_ws: Optional[torch.Tensor] = None):
+def time_attn(q, k_cache, vt_cache, mask: StepMask, *, H, Hkv, d, n_splits: int, reps: int = 20, debug_timeline: bool = False):
     """Mean duration in microseconds of one attention launch (+combine), measured with hipEvents on the launch stream
     inside the library.  k_cache / vt_cache may be LISTS of caches: they are used round-robin, one per repetition, so
     that with enough of them (total > the 256 MB Infinity Cache) every launch streams its K/V from HBM like the
@@ -133,7 +121,7 @@ def time_attn(q, k_cache, vt_cache, mask: StepMask, *, H, Hkv, d, n_splits: int,
     arr = (AttnArgs * len(ks))()
     for i, (k, v) in enumerate(zip(ks, vs)):
         arr[i] = AttnArgs(ptr(q), ptr(k), ptr(v), ptr(out), ptr(part_o), ptr(part_ml), None, q.stride(0), out.stride(0),
-                          H, Hkv, d, S_max, dtype_code(q), n_splits, 1.0 / math.sqrt(d), mask.c_struct(), ptr(merge_ws))
+                          H, Hkv, d, S_max, dtype_code(q), n_splits, 1.0 / math.sqrt(d), mask.c_struct())
     us = C.c_float(0.0)
     if len(ks) == 1:
         call("lade_time_attn", C.byref(arr[0]), reps, C.byref(us))

@@ -19,7 +19,6 @@ def main():
     ap.add_argument("--Hkv", type=int, default=32)
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--reps", type=int, default=400)
-    ap.add_argument("--merge", default="xcd", choices=["xcd", "launch"], help="split merge inside the attention launch (engine default) or as a second launch")
     ap.add_argument("--resident", action="store_true", help="one K/V cache, re-read every repetition (stays in the Infinity Cache)")
     ap.add_argument("--lp-rank", action="store_true", help="a lookahead-parallel rank's step instead of the full window: 4 re-fed inputs, "
                     "columns 12..14 of the W=15 window, 2 candidates (T = 31; with --H 64 --Hkv 8 this is config 5's rank shape)")
@@ -43,11 +42,10 @@ def main():
                 T = mask.T
                 q = torch.randn(T, (a.H + 2 * a.Hkv) * a.d, device="cuda").bfloat16()
             alg = 2 * (2 * a.Hkv * (P + T) * a.d + 2 * a.H * T * a.d)
-            ws = ops.new_merge_ws("cuda") if a.merge == "xcd" else None
             for ns in a.splits:
                 n = ns if ns > 0 else ops.choose_splits(a.H, a.H // a.Hkv, T, P + T)
                 if os.environ.get("LADE_ATTN_DBG") == "16":
-                    us, tl = ops.time_attn(q, k, vt, mask, H=a.H, Hkv=a.Hkv, d=a.d, n_splits=n, reps=a.reps, debug_timeline=True, merge_ws=ws)
+                    us, tl = ops.time_attn(q, k, vt, mask, H=a.H, Hkv=a.Hkv, d=a.d, n_splits=n, reps=a.reps, debug_timeline=True)
                     br = ops.attn_block_rows(a.H // a.Hkv, T) if not os.environ.get('LADE_ATTN_SHAPE') else int(os.environ['LADE_ATTN_SHAPE'])
                     nwg = a.Hkv * n * ((T * (a.H // a.Hkv) + br - 1) // br)
                     tl = tl[:nwg].double()
@@ -61,10 +59,8 @@ def main():
                     print("   stamps (cycles since WG start) mean:", [int(x) for x in rel.mean(0).tolist()], "max:", [int(x) for x in rel.max(0)[0].tolist()],
                           " WG start spread:", int(tl[:, 0].max() - tl[:, 0].min()), " kernel span:", int(tl[:, 6].max() - tl[:, 0].min()))
                 else:
-                    us = ops.time_attn(q, k, vt, mask, H=a.H, Hkv=a.Hkv, d=a.d, n_splits=n, reps=a.reps, merge_ws=ws)
-                if ws is not None and ops.merge_ws_error(ws):
-                    print("   MERGE ERROR WORD SET")
-                print(f"merge={a.merge:6s} H={a.H:3d}/{a.Hkv:2d} T={T:4d} P={P:5d} splits={n:3d}  {us:8.2f} us   {alg / us / 1e3:8.1f} GB/s  ({alg / us / 1e3 / 8000 * 100:5.1f}% of 8 TB/s)", flush=True)
+                    us = ops.time_attn(q, k, vt, mask, H=a.H, Hkv=a.Hkv, d=a.d, n_splits=n, reps=a.reps)
+                print(f"H={a.H:3d}/{a.Hkv:2d} T={T:4d} P={P:5d} splits={n:3d}  {us:8.2f} us   {alg / us / 1e3:8.1f} GB/s  ({alg / us / 1e3 / 8000 * 100:5.1f}% of 8 TB/s)", flush=True)
 
 
 if __name__ == "__main__":
