@@ -69,6 +69,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip plain_decode / hot_regime / graph_delta (profiling runs)")
     ap.add_argument("--cpu-baseline-steps", type=int, default=3)
+    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps: the first is the reported value, the others give the spread")
     return ap.parse_args(argv)
 
 
@@ -94,16 +95,19 @@ def attn_useful_flops(cfg, T, P, W, N, g):
     return 4 * cfg["head_dim"] * cfg["heads"] * (T * P + vis)
 
 
-def pmc_traffic(T, P, n_splits):
+def pmc_traffic(cfg, T, P, n_splits):
     """HBM bytes per launch pair from the rocprofv3 PMC passes committed under profiles/ (bench.py cannot collect counters
     itself): FETCH_SIZE (x2 on gfx950 for wide coalesced reads, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KiB -> bytes,
-    attention + combine kernels.  Only reported when a profiled shape matches this run's shape; returns (bytes, source file)."""
-    for name in ("r2_attn_pmc.json", "r1_attn_pmc.json"):
+    attention + combine kernels.  Only reported when a profiled launch has THIS run's shape - heads, KV heads, head size, T, split
+    count, and the cache length within 128 keys; returns (bytes, source file)."""
+    H, Hkv, d = cfg["heads"], cfg["kv_heads"], cfg["head_dim"]
+    for name in ("r3_attn_pmc.json", "r2_attn_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as f:
                 for e in json.load(f)["entries"]:
-                    if e["T"] == T and abs(e["P"] - P) <= 128 and e["n_splits"] == n_splits:      # 128 keys = 2 MB of 36: within the counters' spread
+                    shape = (e.get("H", 32), e.get("Hkv", 32), e.get("d", 128))       # round-2 entries: the 7B heads
+                    if shape == (H, Hkv, d) and e["T"] == T and abs(e["P"] - P) <= 128 and e["n_splits"] == n_splits:      # 128 keys = 2 MB of 36: within the counters' spread
                         return e["traffic_bytes"], f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/attn_bench.py at this shape; not collected by this run)"
         except Exception:
             pass
@@ -128,36 +132,22 @@ def _oracle():
     return O
 
 
-def cpu_baseline_full_depth(c, cfg_full, prompt_len, n_steps):
-    """the reference's CPU greedy path at FULL depth on this box's cores.  The reference itself cannot
-    travel here; its port (oracle/lade_oracle.py, pinned to reference-generated traces) is timed: fp32 weights of the full model
-    (27 GB for the 7B shape), a KV cache of the bench's own prompt length filled with synthetic rows (the timing of a steady step
-    does not depend on the cached values; prefilling 2048 tokens on the CPU would take minutes), then `n_steps` steady lookahead
-    steps (model_step = jforward_multilevel: dense fp32 mask, torch.cat of the cache, lm_head rows, as the reference does).
-    Returns None when the host does not have the memory."""
-    O = _oracle()
+def _cpu_steady_step(O, c, cfg, prompt_len, n_steps):
+    """seconds per steady lookahead step of the oracle on a model of `cfg` (fp32 weights built here), with a KV cache of prompt_len
+    synthetic rows (the timing of a steady step does not depend on the cached values; prefilling 2048 tokens on the CPU would take
+    minutes): model_step = jforward_multilevel - dense fp32 mask, torch.cat of the cache, lm_head rows, as the reference does."""
     from lookaheaddecoding_amd.weights import weight_shapes
-    n_param = sum(int(torch.tensor(s).prod()) for s in weight_shapes(cfg_full).values())
-    need = n_param * 4 * 1.15 + 4e9
-    try:
-        import psutil
-        if psutil.virtual_memory().available < need:
-            return None
-    except Exception:
-        return None
-    cores = host_cores()
-    torch.set_num_threads(cores)
-    W, N, G = c["W"], c["N"], c["G"]
+    W, N = c["W"], c["N"]
     gs = N - 1
     g = torch.Generator().manual_seed(0)
     w = {}
     t_build = time.time()
-    for k, shp in weight_shapes(cfg_full).items():
+    for k, shp in weight_shapes(cfg).items():
         w[k] = torch.ones(shp) if len(shp) == 1 else torch.empty(shp).normal_(0, 0.02, generator=g)
-    model = O.OracleLlama(dict(cfg_full, max_pos=prompt_len + 512), w)
+    model = O.OracleLlama(dict(cfg, max_pos=prompt_len + 512), w)
     cache = [[torch.randn(model.Hkv, prompt_len, model.d, generator=g), torch.randn(model.Hkv, prompt_len, model.d, generator=g)] for _ in range(model.L)]
     t_build = time.time() - t_build
-    rnd = lambda n: torch.randint(3, cfg_full["vocab"], (n,), generator=g).tolist()
+    rnd = lambda n: torch.randint(3, cfg["vocab"], (n,), generator=g).tolist()
     past = [rnd(W - 1)] + [rnd(W) for _ in range(N - 2)]
     times, T = [], 0
     for i in range(1 + n_steps):
@@ -169,60 +159,45 @@ def cpu_baseline_full_depth(c, cfg_full, prompt_len, n_steps):
         O.kv_truncate(cache, prompt_len)
         if i > 0:                                  # the first call pays page faults / thread pool start-up
             times.append(dt)
-    step_s = sum(times) / len(times)
     del model, w, cache
-    return {"value": round(1.0 / step_s, 4), "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/lade_oracle.py (port of lade/decoding.py:697-1259 + modeling_llama.py eager path), fp32, {cores} threads, FULL depth "
-                      f"({cfg_full['layers']} layers, {n_param * 4 / 1e9:.1f} GB of weights built in {t_build:.0f} s), KV cache of {prompt_len} synthetic rows, "
-                      f"{n_steps} steady steps of T={T} tokens after one untimed step, W={W} N={N} G={G}, S=1.0 (cold regime: 1 token/step)",
-            "s_per_step": round(step_s, 4)}
+    return sum(times) / len(times), T, t_build
 
 
-def cpu_baseline_sliced(c, cfg_full, model_name, n_steps):
-    """Layer-sliced sample for the shapes whose full depth does not fit the time budget (13B / 70B): 1- and 2-layer models of the
-    same widths, short prompt, a few steady steps of the oracle loop; the per-layer time is extrapolated to the full depth."""
+def cpu_baseline(c, cfg_full, prompt_len, n_steps, allow_full=True):
+    """the reference's CPU greedy path on this box's cores.  The reference itself cannot travel here; its
+    port (oracle/lade_oracle.py, pinned to reference-generated traces) is timed on steady lookahead steps at the bench's own prompt
+    length.  FULL depth when the fp32 model fits the host's memory and the time budget (the 7B shape: 27 GB, ~2 s / step);
+    otherwise (13B / 70B shapes) the same widths at 2 and 4 layers, the per-layer time extrapolated to the full depth."""
     O = _oracle()
     from lookaheaddecoding_amd.weights import make_config, weight_shapes
     cores = host_cores()
     torch.set_num_threads(cores)
     W, N, G = c["W"], c["N"], c["G"]
-    prompt_len = 64
-    times = {}
-    for Ls in (1, 2):
-        cfg = make_config(cfg_full, layers=Ls, max_pos=1024)
-        g = torch.Generator().manual_seed(0)
-        w = {}
-        for k, shp in weight_shapes(cfg).items():
-            w[k] = torch.ones(shp) if len(shp) == 1 else torch.empty(shp).normal_(0, 0.02, generator=g)
-        model = O.OracleLlama(cfg, w)
-        prompt = torch.randint(3, cfg["vocab"], (prompt_len,), generator=torch.Generator().manual_seed(123)).tolist()
-        total = (N - 1) + n_steps
-        t_marks = []
-        orig = O.model_step
-
-        def timed_step(*a, **k):
-            t0 = time.time()
-            r = orig(*a, **k)
-            t_marks.append((time.time() - t0, r.layout.T))
-            return r
-
-        O.model_step = timed_step
+    n_param = sum(int(torch.tensor(s).prod()) for s in weight_shapes(cfg_full).values())
+    head = "oracle/lade_oracle.py (port of lade/decoding.py:697-1259 + modeling_llama.py eager path), fp32"
+    fits = False
+    if allow_full:
         try:
-            O.lookahead_greedy(model, prompt, W, N, G, prompt_len + total, random.Random(1), keep_trace=False)
-        finally:
-            O.model_step = orig
-        steady = t_marks[N - 1:]
-        times[Ls] = (sum(t for t, _ in steady) / max(1, len(steady)), sum(T for _, T in steady) / max(1, len(steady)))
-        del model, w
-    per_layer = max(times[2][0] - times[1][0], 1e-9)
-    fixed = max(times[1][0] - per_layer, 0.0)
-    step_s = fixed + cfg_full["layers"] * per_layer
-    return {"value": round(1.0 / step_s, 4), "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/lade_oracle.py (port of lade/decoding.py:697-1259 + modeling_llama.py eager path), fp32, {cores} threads; layer-sliced "
-                      f"{model_name} shape (1 and 2 layers -> per-layer {per_layer * 1e3:.1f} ms, fixed {fixed * 1e3:.1f} ms, scaled x{cfg_full['layers']} layers = "
-                      f"{step_s:.2f} s/step; full depth not run: {cfg_full['layers']} layers of this width exceed the bench's CPU time budget), prompt {prompt_len}, "
-                      f"{n_steps} steady steps, W={W} N={N} G={G}, T~{times[2][1]:.0f} tokens/step, S=1.0 (cold regime: 1 token/step)",
-            "s_per_step": round(step_s, 4)}
+            import psutil
+            fits = psutil.virtual_memory().available >= n_param * 4 * 1.15 + 4e9 and n_param < 8e9
+        except Exception:
+            fits = False
+    if fits:
+        step_s, T, t_build = _cpu_steady_step(O, c, cfg_full, prompt_len, n_steps)
+        sample = (f"{head}, {cores} threads, FULL depth ({cfg_full['layers']} layers, {n_param * 4 / 1e9:.1f} GB of weights built in {t_build:.0f} s), "
+                  f"KV cache of {prompt_len} synthetic rows, {n_steps} steady steps of T={T} tokens after one untimed step, W={W} N={N} G={G}, S=1.0 (cold regime: 1 token/step)")
+    else:
+        t = {}
+        for Ls in (2, 4):
+            t[Ls], T, _ = _cpu_steady_step(O, c, make_config(cfg_full, layers=Ls), prompt_len, max(2, n_steps - 1))
+        per_layer = max((t[4] - t[2]) / 2, 1e-9)
+        fixed = max(t[2] - 2 * per_layer, 0.0)
+        step_s = fixed + cfg_full["layers"] * per_layer
+        sample = (f"{head}, {cores} threads; the full widths at 2 and 4 layers (steady steps {t[2]:.2f} s and {t[4]:.2f} s -> {per_layer * 1e3:.0f} ms per layer, "
+                  f"{fixed * 1e3:.0f} ms of lm_head / embedding) scaled to {cfg_full['layers']} layers = {step_s:.2f} s/step (full depth, {n_param * 4 / 1e9:.0f} GB in fp32, "
+                  f"is beyond the bench's memory / time budget), KV cache of {prompt_len} synthetic rows, steady steps of T={T} tokens, W={W} N={N} G={G}, "
+                  f"S=1.0 (cold regime: 1 token/step)")
+    return {"value": round(1.0 / step_s, 4), "unit": "tokens/s", "cores": cores, "kind": "port", "sample": sample, "s_per_step": round(step_s, 4)}
 
 
 def worker(args):
@@ -260,6 +235,8 @@ def worker(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group spans {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
     from lookaheaddecoding_amd import ops
     from lookaheaddecoding_amd.decoding import LookaheadDecoder
@@ -273,7 +250,7 @@ def worker(args):
         cfg["layers"] = args.layers
     W, N, G = c["W"], c["N"], c["G"]
     gs = N - 1
-    total_steps = (N - 1) + args.warmup + args.steps + 8
+    total_steps = (N - 1) + args.warmup + args.steps * max(1, args.blocks) + 16
     max_seq = args.prompt_len + total_steps * N + (N - 1) * (W + G) + 64
     cfg["max_pos"] = max(cfg.get("max_pos", 4096), max_seq)
     weights = random_weights_torch(cfg, seed=0, dtype=dtype, device=dev)
@@ -310,6 +287,14 @@ def worker(args):
         run = LPRunner(dec)
     elif sampling:
         run = SampleRun(dec)
+    # ranks the step's collective really spans: the process group's size, or ncclCommCount of the C ABI's own communicator
+    collective_ranks, collective_kind = 1, "none"
+    if use_lp:
+        comm = getattr(run, "comm", None)
+        collective_ranks = comm.count() if comm is not None else dist.get_world_size()
+        collective_kind = ("lade_lp_allgather (C ABI, RCCL)" if comm is not None else f"torch.distributed all_gather_into_tensor ({backend}{' = RCCL' if backend == 'nccl' else ''})")
+        if collective_ranks != args.gpus:
+            raise SystemExit(f"the step's collective spans {collective_ranks} ranks, --gpus {args.gpus}")
     run.start(prompt, rng=random.Random(1))
     run.step()                                   # untimed: first-call costs (GEMM autotune of the last chunk's row class, library handles)
     run.start(prompt, rng=random.Random(1))
@@ -336,6 +321,25 @@ def worker(args):
         elapsed, prefill_s = float(tmax[0].item()), float(tmax[1].item())
     new_tokens = len(run.tokens) - tok0
     S = new_tokens / args.steps
+    # the contract's number is the block above (exactly K steps).  Four more blocks of K steps follow for the spread: the boxes of the
+    # pool drift by several per cent between consecutive runs of one binary, a single 80 ms block says nothing about that
+    block_ms = [elapsed / args.steps * 1e3]
+    for _ in range(max(0, args.blocks - 1)):
+        sync()
+        tb0 = time.perf_counter()
+        for _ in range(args.steps):
+            run.step()
+        sync()
+        tb = time.perf_counter() - tb0
+        if use_lp:
+            tb_t = torch.tensor([tb], device=dev, dtype=torch.float64)
+            dist.all_reduce(tb_t, op=dist.ReduceOp.MAX)
+            tb = float(tb_t[0].item())
+        block_ms.append(tb / args.steps * 1e3)
+    srt = sorted(block_ms)
+    spread = {"blocks": len(block_ms), "steps_per_block": args.steps, "ms_per_step_median": round(srt[len(srt) // 2], 3), "ms_per_step_min": round(srt[0], 3),
+              "ms_per_step_max": round(srt[-1], 3), "ms_per_step_blocks": [round(x, 3) for x in block_ms],
+              "note": "block 0 is the contract's timed region (value / ms_per_step); the others follow it back to back"}
     Ts = [i["T"] for i in infos if i.get("T")]
     avg_T = (sum(Ts) / len(Ts)) if Ts else float((N - 1) * W)
     P_end = run.P
@@ -348,7 +352,7 @@ def worker(args):
         was_graph, dec.use_graph = dec.use_graph, False
         run.step()                                   # first eager step: one-off costs (autotune of a new row class ...)
         sync()
-        eng.attn_events = []
+        eng.attn_events, eng.attn_events_empty = [], []
         te0 = time.perf_counter()
         for _ in range(4):
             run.step()
@@ -358,11 +362,16 @@ def worker(args):
         T_ref = int(round(avg_T))
         evs = [e for e in evs if e[2] == T_ref] or evs           # launches of the steady shape only (a stray candidate changes T)
         durs = sorted(e0.elapsed_time(e1) * 1e3 for (e0, e1, _, _) in evs)
+        # what an EMPTY bracket reads: every layer also records two events back to back right before the attention bracket
+        empt = sorted(a0.elapsed_time(a1) * 1e3 for (a0, a1) in (eng.attn_events_empty or []))
+        eng.attn_events_empty = None
+        ev_overhead = empt[len(empt) // 2] if empt else 0.0
         if durs:
             # eager launches keep the GPU busy only when a step's GPU time exceeds its host launch time; otherwise the bracket also
             # contains host gaps (small models) and the graph difference / isolated timing is reported instead
             gpu_bound = eager_ms <= 1.15 * (elapsed / args.steps * 1e3)
-            in_situ = {"us": sum(durs) / len(durs), "median_us": durs[len(durs) // 2], "T": evs[-1][2], "n_splits": evs[-1][3], "P": run.P,
+            in_situ = {"us": sum(durs) / len(durs) - ev_overhead, "us_raw_bracket": sum(durs) / len(durs), "empty_bracket_us": ev_overhead,
+                       "median_us": durs[len(durs) // 2] - ev_overhead, "T": evs[-1][2], "n_splits": evs[-1][3], "P": run.P,
                        "launches": len(durs), "eager_ms_per_step": round(eager_ms, 3), "gpu_bound": bool(gpu_bound)}
 
     # ---- the same pair as a step-time difference: a second decoder over the same engine with the attention launches left out,
@@ -416,6 +425,39 @@ def worker(args):
     # zeroed (the residual stream keeps the input embedding) and lm_head row j set to embed[(j-1) mod C] for j < C, so the greedy
     # continuation of token t is (t+1) mod C; the prompt walks that cycle and POOL_FROM_PROMPT seeds the pool, so every step
     # verifies a full n-gram (S -> N-1).  Same kernels, same bytes.
+    # ---- hot regime with LIVE weights: the embedding is scaled up (x50: the same order as a layer's contribution to the
+    # residual stream) and tied to the lm_head, which makes the random model copy-biased - on a periodic prompt its greedy continuation
+    # keeps repeating what it has seen, the pool hits, and S is whatever the model yields; every projection, the attention and the MLP
+    # feed the logits (tests/test_gpu_parity_shapes.py: test_full_width_real_weights_bf16_with_accepted_ngrams).  The lookahead stream is
+    # checked against plain greedy decoding on the same engine.
+    def hot_live():
+        eng.embed.mul_(50.0)
+        saved_head, eng.lm_head = eng.lm_head, eng.embed
+        live_prompt = [(7 * i) % 50 + 3 for i in range(args.prompt_len)]
+        ld = LookaheadDecoder(eng, W, N, G, pool_from_prompt=True, use_graph=not args.no_graph)
+        ld.start(live_prompt, rng=random.Random(1))
+        for _ in range(N - 1 + args.warmup):
+            ld.step()
+        sync()
+        tok_l = len(ld.tokens)
+        tl0 = time.perf_counter()
+        li = [ld.step() for _ in range(args.steps)]
+        sync()
+        tl = time.perf_counter() - tl0
+        gen_all = ld.tokens[len(live_prompt):]
+        n_chk = min(len(gen_all), 64)
+        plain_ref = eng.plain_greedy(live_prompt, len(live_prompt) + n_chk)[len(live_prompt):]
+        n_same = next((i for i, (x, y) in enumerate(zip(gen_all, plain_ref)) if x != y), n_chk)
+        out_l = {"value": round((len(ld.tokens) - tok_l) / tl, 2), "unit": "tokens/s", "step_compression": round((len(ld.tokens) - tok_l) / args.steps, 3),
+                 "ms_per_step": round(tl / args.steps * 1e3, 3), "tokens_per_step_T": round(sum(i["T"] for i in li) / len(li), 1),
+                 "equals_plain_greedy_for": f"{n_same} of the first {n_chk} generated tokens",
+                 "how": "live weights: embedding x50 tied to lm_head (copy-biased random model, attention / MLP / every projection feed the logits), periodic "
+                        "prompt (period 50), POOL_FROM_PROMPT=1; S is the model's own acceptance rate; stream compared with plain greedy on the same engine "
+                        "(bf16: the two may part where two logits tie within rounding)"}
+        eng.lm_head = saved_head
+        eng.embed.mul_(1.0 / 50.0)
+        return out_l
+
     def hot_regime():
         Cy = 256
         for lw in eng.layers:
@@ -440,7 +482,8 @@ def worker(args):
         return {"value": round(len(gen) / th, 2), "unit": "tokens/s", "step_compression": round(len(gen) / args.steps, 3),
                 "ms_per_step": round(th / args.steps * 1e3, 3), "tokens_per_step_T": round(sum(i["T"] for i in hot_infos) / len(hot_infos), 1),
                 "output_is_the_successor_cycle": ok,
-                "how": "successor-map model (o_proj/down_proj zeroed, lm_head = shifted embedding), cyclic prompt, POOL_FROM_PROMPT=1"}
+                "how": "upper bound of the accept path: successor-map model (o_proj/down_proj zeroed, lm_head = shifted embedding), cyclic prompt, "
+                       "POOL_FROM_PROMPT=1 - every step verifies a full n-gram (S = N-1)"}
 
     if rank == 0:
         # ---- roofline of the dominant hand-written kernel: lookahead attention, one layer ----
@@ -469,7 +512,7 @@ def worker(args):
         alg = attn_algorithmic_bytes(cfg, T_k, P_end)
         flops = attn_useful_flops(cfg, T_k, P_end, W, N, g_mid) if not use_lp else 4 * cfg["head_dim"] * cfg["heads"] * T_k * P_end
         achieved = alg / (us * 1e-6) / 1e9
-        traffic, traffic_source = pmc_traffic(T_k, P_end, ns)
+        traffic, traffic_source = pmc_traffic(cfg, T_k, P_end, ns)
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
                     "traffic": traffic, "traffic_source": traffic_source,
                     "kernel": f"lade::attn_fwd_kernel<{args.dtype},{cfg['head_dim']}> (+combine, n_splits={ns})",
@@ -481,16 +524,15 @@ def worker(args):
                     "launch_us_graph_delta": None if graph_delta is None else {k: (round(v, 2) if isinstance(v, float) else v) for k, v in graph_delta.items()},
                     "launch_us_isolated": round(us_iso, 2),
                     "note": "launch_us = one layer's launch pair (attention + split merge): bracketed by hipEvents on the launch stream INSIDE real decode "
-                            "steps (4 eager steady steps after the timed region, every layer; used when those steps are GPU bound), else (graph step "
+                            "steps (4 eager steady steps after the timed region, every layer; minus what an empty bracket - two events recorded back to back "
+                            "in the same place - reads, launch_us_in_step.empty_bracket_us; used when those steps are GPU bound), else (graph step "
                             "time - graph step time without the attention launches) / layers, else isolated back-to-back launches cycling through the "
                             "layers' K/V caches (every launch reads HBM)"}
-        hot = hot_regime() if extras else None
+        hot_l = hot_live() if extras else None
+        hot = hot_regime() if extras else None          # last: it zeroes o_proj / down_proj
         cpu = None
         if not args.no_cpu_baseline and world == 1:            # the CPU baseline is timed at N=1 only
-            if args.config in ("c2", "c3") and not args.layers:
-                cpu = cpu_baseline_full_depth(c, cfg, args.prompt_len, args.cpu_baseline_steps)
-            if cpu is None:
-                cpu = cpu_baseline_sliced(c, cfg, c["model"], args.cpu_baseline_steps)
+            cpu = cpu_baseline(c, cfg, args.prompt_len, args.cpu_baseline_steps, allow_full=not args.layers)
         mode = "sampling (temperature %.2f)" % c["temperature"] if sampling else "greedy"
         out = {
             "metric": f"tokens/s, {mode} lookahead decoding (W={W},N={N},G={G})",
@@ -499,13 +541,14 @@ def worker(args):
             "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (random-init weights, random prompt ids)",
             "config": {"workload": f"{c['what']}; {c['model']}-shape ({cfg['layers']}L) {args.dtype} {mode} lookahead, 1 sequence, prompt {args.prompt_len}, "
                                    f"W={W} N={N} G={G}, cold regime (untied random weights)", "name": args.config,
-                       "parallelism": f"lp{world}" if use_lp else "single", "tokens_per_step_T": round(avg_T, 1), "kv_len_end": P_end,
+                       "parallelism": f"lp{world}" if use_lp else "single", "collective_ranks": collective_ranks, "collective": collective_kind,
+                       "tokens_per_step_T": round(avg_T, 1), "kv_len_end": P_end,
                        "hipgraph": bool(dec.use_graph), **({"shared_gpu": True, "backend": backend} if share_gpu else {})},
-            "step_compression": round(S, 3), "steps_per_s": round(args.steps / elapsed, 2),
+            "step_compression": round(S, 3), "steps_per_s": round(args.steps / elapsed, 2), "spread": spread,
             "prefill": {"tokens": args.prompt_len + W + N - 3, "ms": round(prefill_s * 1e3, 2), "tokens_per_s": round((args.prompt_len + W + N - 3) / prefill_s, 1),
                         "how": f"prompt + first window level as causal chunks of <= {args.chunk} rows through the same attention / GEMM kernels, lm_head on the "
                                "rows that are read only; second prefill of the process (the first one pays the one-off GEMM autotune)"},
-            "hot_regime": hot, "plain_decode": plain, "roofline": roofline,
+            "hot_regime": hot_l, "hot_regime_forced": hot, "plain_decode": plain, "roofline": roofline,
             # the whole step against the same HBM peak: the bytes a step cannot avoid reading (weights + K/V cache + lm_head) / its time
             "step_stream": {"bound": "hbm", "bytes_per_step": step_stream_bytes(cfg, P_end, 1), "achieved": round(step_stream_bytes(cfg, P_end, 1) / (elapsed / args.steps) / 1e9, 1),
                             "peak": 8000.0, "unit": "GB/s", "frac": round(step_stream_bytes(cfg, P_end, 1) / (elapsed / args.steps) / 1e9 / 8000.0, 4),

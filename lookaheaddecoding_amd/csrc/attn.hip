@@ -47,7 +47,8 @@ struct AttnK {
     float scale_log2;   // scale * log2(e)
     int dbg;
     // work-group -> (row block, KV head, split) decode of the 1-D grid (see block_decode): magic multipliers for / n_splits and / Hkv
-    uint32_t ns_magic, hkv_magic;
+    uint32_t ns_magic, hkv_magic, t_magic;          // ... and / T (row -> head-in-group)
+    float inv_T;        // 1 / T, rounded once on the host
     int n_groups;       // row blocks x KV heads
     lade_mask_params m;
 };
@@ -331,16 +332,16 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
         // plain causal rows (prefill chunks, modeling_llama.py:124-130): no row of this block sees a key beyond its last token, so
         // the tiles behind it are neither requested nor computed - the splits of the block partition only what it can see
         const int r0 = rbk * ROWS, r1 = min(r0 + ROWS, n_rep * m.T) - 1;
-        const int hg0 = r0 / m.T, hg1 = r1 / m.T;
+        const int hg0 = (int)div_magic((uint32_t)r0, a.t_magic), hg1 = (int)div_magic((uint32_t)r1, a.t_magic);
         const int tmax = hg0 != hg1 ? m.T - 1 : r1 - hg1 * m.T;
         n_tiles = min(n_tiles, (m.P + tmax + 1 + KT - 1) / KT);
     }
     int base, stride, my_tiles;
     if (a.dbg & 64) {                               // interleaved: splits differ by at most one tile
         base = sp; stride = ns;
-        my_tiles = sp < n_tiles ? (n_tiles - sp + ns - 1) / ns : 0;
+        my_tiles = sp < n_tiles ? (int)div_magic((uint32_t)(n_tiles - sp + ns - 1), a.ns_magic) : 0;
     } else {                                        // contiguous key ranges
-        const int tps = (n_tiles + ns - 1) / ns;
+        const int tps = (int)div_magic((uint32_t)(n_tiles + ns - 1), a.ns_magic);       // no integer division on the way to the first DMA
         base = sp * tps; stride = 1;
         my_tiles = max(0, min(base + tps, n_tiles) - base);
     }
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
     for (int ts = 0; ts < TPS; ++ts) issue_tiles(0, ts, ts < my_tiles ? base + ts * stride : base);
 
     const int n_rows = n_rep * m.T;
-    const float invT = 1.0f / (float)m.T;
+    const float invT = a.inv_T;
     // row r of the (head-in-group, token) row space -> (hg, t); exact for r < 4096, T <= 512
     auto split_row = [&](int r, int& hg, int& t) {
         if (n_rep == 1) { hg = 0; t = r; }
@@ -384,6 +385,9 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
 #pragma unroll
     for (int i = 0; i < QPW; ++i) {
         const int piece = wave * QPW + i;
+        // a 32-row group without any row (a steady 7B step has 60 rows: groups 2 and 3 of the 128-row block) is not requested at all:
+        // its waves never read it (wave_rows below).  Pieces are wave uniform, the counted waits below do not depend on how many a wave issued.
+        if (rbk * ROWS + (piece * (64 / K_CPR) / 32) * 32 >= n_rows) continue;
         const int row = piece * (64 / K_CPR) + lane / K_CPR;
         const int c = (lane % K_CPR) ^ swz16<2 * D>(row);
         int r = rbk * ROWS + row, hg, t;
@@ -589,7 +593,7 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
         dbg_stamp(a, 4);
         l_run += __shfl_xor(l_run, 32);
         unsigned char* stg = stg_base + (size_t)rg * STG_STRIDE;
-        const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+        const float inv = l_run > 0.f ? __builtin_amdgcn_rcpf(l_run) : 0.f;      // 1 ulp; the result is rounded to 16 bits
 #pragma unroll
         for (int db = 0; db < DBLK; ++db)
 #pragma unroll
@@ -730,7 +734,8 @@ static AttnK make_k(const lade_attn_args* a) {
     k.out = (uint16_t*)a->out; k.part_o = (uint16_t*)a->part_o; k.part_ml = a->part_ml; k.dyn_P = a->dyn_P;
     k.q_row_stride = a->q_row_stride; k.out_row_stride = a->out_row_stride;
     k.H = a->H; k.Hkv = a->Hkv; k.S_max = a->S_max; k.n_splits = a->n_splits; k.n_rep = a->H / a->Hkv;
-    k.ns_magic = magic_for(a->n_splits); k.hkv_magic = magic_for(a->Hkv);
+    k.ns_magic = magic_for(a->n_splits); k.hkv_magic = magic_for(a->Hkv); k.t_magic = magic_for(a->mask.T);
+    k.inv_T = 1.0f / (float)a->mask.T;
     k.n_groups = 0;                                 // set per work-group shape (launch_fwd_shape)
     k.scale_log2 = a->scale * 1.4426950408889634f;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("LADE_ATTN_DBG"); dbg = e ? atoi(e) : 0; } k.dbg = dbg; }

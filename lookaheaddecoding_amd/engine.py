@@ -133,6 +133,7 @@ class StepEngine:
                 wd=W(p + "wd").contiguous()))
         self._alloc_cache(self.S_max)
         self.attn_events = None             # set to a list to collect (start, end, T, n_splits) hipEvent pairs per layer
+        self.attn_events_empty = None       # ... and back-to-back event pairs (what an empty bracket reads)
         self.skip_attn = False              # bench.py only: leave the attention launches out (step-time difference = their cost)
         self.max_splits = 32
         # hand-written weight-streaming GEMM (split-K partials consumed by the fused glue kernels) for steps of
@@ -382,6 +383,11 @@ class StepEngine:
                 q_in = qkv
             ev = None if self.skip_attn else self.attn_events      # skip_attn: `o` keeps stale values, the logits are meaningless
             if ev is not None:              # bench.py: hipEvents around the attention launch pair, in the real step
+                if self.attn_events_empty is not None:      # calibration: what two events recorded back to back read here
+                    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    c0.record()
+                    c1.record()
+                    self.attn_events_empty.append((c0, c1))
                 e0 = torch.cuda.Event(enable_timing=True)
                 e0.record()
             if not self.skip_attn:

@@ -22,8 +22,10 @@ def main():
     ap.add_argument("--resident", action="store_true", help="one K/V cache, re-read every repetition (stays in the Infinity Cache)")
     ap.add_argument("--lp-rank", action="store_true", help="a lookahead-parallel rank's step instead of the full window: 4 re-fed inputs, "
                     "columns 12..14 of the W=15 window, 2 candidates (T = 31; with --H 64 --Hkv 8 this is config 5's rank shape)")
+    ap.add_argument("--W", type=int, default=15)
+    ap.add_argument("--N", type=int, default=5)
     a = ap.parse_args()
-    W, N = 15, 5
+    W, N = a.W, a.N
     gs = N - 1
     for T in a.T:
         g = max(0, (T - (N - 1) * W) // gs)
