@@ -37,6 +37,7 @@
  *   lade_softmax_rows / lade_softmax_gather   probabilities of the sampling verify: one full row (the distribution a token is
  *                            finally drawn from) / the per-candidate draft probabilities of the acceptance loop, gathered on
  *                            the device without materialising guess_probs   lade/decoding.py:484-540
+ *   lade_warp_rows           temperature / top-k / top-p warpers in one launch   lade/decoding.py:375-377, :443, :488
  *   lade_rmsnorm / lade_add_rmsnorm / lade_silu_mul / lade_gather_rows   LlamaRMSNorm (+ residual add), SwiGLU,
  *                            embedding / logits-row gather around the GEMMs
  *                            lade/models/modeling_llama.py:222-227, :360-380, :1164 ("next" row)
@@ -277,6 +278,15 @@ int lade_softmax_gather(const void* logits, int64_t ld, int32_t rows, int32_t V,
                         const int32_t* guess, const int32_t* g_dev, int32_t g, int32_t gs, int32_t g_cap, float* scal,
                         float* stats, void* stream);
 
+/* Logits warpers of the sampling path in one launch (lade/decoding.py:375-377: the reference admits exactly HF's Temperature, TopK and
+ * TopP warpers, applied in that order through LogitsProcessorList at :443 / :488):  out[r][:] = top_p(top_k(logits[r'][:] / temperature))
+ * in fp32 with removed tokens set to -inf, r' = r for r = 0 and r + skip behind it (the same row addressing as lade_softmax_gather).
+ * top_k = 0 and top_p >= 1 switch the respective filter off.  Tie rules of the HF warpers: values equal to the k-th largest stay; the
+ * nucleus cut walks the ascending order with ties in token order and always keeps the last token.  V <= 32768 (one work-group holds a
+ * row in registers); larger vocabularies return LADE_E_LIMIT. */
+int lade_warp_rows(const void* logits, int64_t ld, int32_t rows, int32_t V, int32_t dtype, float temperature, int32_t top_k,
+                   float top_p, int32_t skip, float* out, void* stream);
+
 /* ---- glue around the GEMMs -------------------------------------------------------------- */
 /* y = weight * (x * rsqrt(mean(x^2) + eps)) with the reference's rounding (fp32 norm, cast, then * weight) */
 int lade_rmsnorm(const void* x, const void* weight, void* y, int32_t rows, int32_t hidden, float eps, int32_t dtype,
@@ -284,6 +294,13 @@ int lade_rmsnorm(const void* x, const void* weight, void* y, int32_t rows, int32
 /* y = x + r (residual add) fused with the norm of the sum: x <- x + r ; y = rmsnorm(x) */
 int lade_add_rmsnorm(void* x, const void* r, const void* weight, void* y, int32_t rows, int32_t hidden, float eps,
                      int32_t dtype, void* stream);
+/* The row-pruned tail of a step (the reference norms and projects all T rows, lade/models/modeling_llama.py:1541-1544; only the out row,
+ * the last level's rows and the candidate rows are ever read): y[j] = rmsnorm(x[sel[j]] + res[sel[j]]) for j < n_sel, res = r or the sum of
+ * n_parts fp32 split-K partials (part_stride elements apart) in split order; x is NOT written back.  One launch instead of a partial
+ * fold, two row gathers and a norm. */
+int lade_add_rmsnorm_rows(const void* x, const void* r, const float* parts, int32_t n_parts, int64_t part_stride, const int32_t* sel,
+                          const void* weight, void* y, int32_t n_sel, int32_t src_rows, int32_t hidden, float eps, int32_t dtype,
+                          void* stream);
 /* SwiGLU of LlamaMLP (lade/models/modeling_llama.py:360-380) on the output of the fused gate/up GEMM, rounded like the separate torch ops.
  * layout 0: gu rows are [gate (inter) | up (inter)]: out[r][i] = silu(gu[r][i]) * gu[r][inter + i].
  * layout 1: groups of 16 - [16 gate | their 16 up] per 32 columns: out[r][i] = silu(gu[r][32*(i/16) + i%16]) * gu[r][32*(i/16) + 16 + i%16]

@@ -77,8 +77,10 @@ SIGNATURES = {
     "lade_lp_comm_destroy": [_vp],
     "lade_softmax_rows": [_vp, _i64, _i32, _i32, _i32, _f32, _vp, _vp],
     "lade_softmax_gather": [_vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
+    "lade_warp_rows": [_vp, _i64, _i32, _i32, _i32, _f32, _i32, _f32, _i32, _vp, _vp],
     "lade_rmsnorm": [_vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp],
     "lade_add_rmsnorm": [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp],
+    "lade_add_rmsnorm_rows": [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp],
     "lade_silu_mul": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "lade_gather_rows": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "lade_gemm_skinny": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],

@@ -139,10 +139,18 @@ template <typename T> __device__ __forceinline__ float rnd_st(float f) { typenam
 template <typename T, bool ADD, int CH, int BT>
 __global__ __launch_bounds__(BT) void rmsnorm_kernel(typename St<T>::S* x, const typename St<T>::S* r, const typename St<T>::S* w,
                                                      typename St<T>::S* y, int hidden, float eps, const float* parts, int n_parts,
-                                                     size_t part_stride) {
+                                                     size_t part_stride, const int32_t* sel = nullptr, int src_rows = 0) {
     constexpr int N = Vec<T>::N;
     __shared__ float sm[BT / 64];
-    const size_t base = (size_t)blockIdx.x * hidden;
+    // sel: the block's INPUT row is sel[blockIdx.x] (row-pruned tail of the step: only the rows whose logits are read are normed),
+    // its output row is blockIdx.x, and x is not written back
+    size_t base = (size_t)blockIdx.x * hidden;
+    const size_t obase = base;
+    if (sel) {
+        int rsel = sel[blockIdx.x];
+        rsel = rsel < 0 ? 0 : (rsel >= src_rows ? src_rows - 1 : rsel);
+        base = (size_t)rsel * hidden;
+    }
     const int nvec = hidden / N;
     float v[CH][N];
     u32x4 wv[CH];
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(BT) void rmsnorm_kernel(typename St<T>::S* x, const
             if (ADD) {
 #pragma unroll
                 for (int e = 0; e < N; ++e) v[c][e] = rnd_st<T>(v[c][e] + rr[e]);
-                *reinterpret_cast<u32x4*>(x + base + (size_t)i * N) = repack<T>(v[c]);
+                if (!sel) *reinterpret_cast<u32x4*>(x + base + (size_t)i * N) = repack<T>(v[c]);
             }
 #pragma unroll
             for (int e = 0; e < N; ++e) ss += v[c][e] * v[c][e];
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(BT) void rmsnorm_kernel(typename St<T>::S* x, const
             unpack<T>(wv[c], ww);
 #pragma unroll
             for (int e = 0; e < N; ++e) o[e] = ww[e] * rnd_st<T>(v[c][e] * inv);     // weight * hidden.to(dtype)
-            *reinterpret_cast<u32x4*>(y + base + (size_t)i * N) = repack<T>(o);
+            *reinterpret_cast<u32x4*>(y + obase + (size_t)i * N) = repack<T>(o);
         }
     }
 }
@@ -292,13 +300,13 @@ using namespace lade;
 
 template <bool ADD>
 static int launch_rmsnorm(void* x, const void* r, const void* weight, void* y, int rows, int hidden, float eps, int dtype, hipStream_t st,
-                          const float* parts = nullptr, int n_parts = 0, size_t part_stride = 0) {
+                          const float* parts = nullptr, int n_parts = 0, size_t part_stride = 0, const int32_t* sel = nullptr, int src_rows = 0) {
     const int nvec_bytes = dtype == LADE_F32 ? 4 : 8;
     LADE_REQUIRE(hidden % nvec_bytes == 0, LADE_E_ARG, "lade_rmsnorm: hidden=%d must be a multiple of %d", hidden, nvec_bytes);
     const int vecs = hidden / nvec_bytes;              // 16-byte chunks per row
     LADE_REQUIRE(vecs <= 8 * 512, LADE_E_LIMIT, "lade_rmsnorm: hidden=%d too large for the register-resident row", hidden);
 #define RMS_LAUNCH(CH, BT) DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((rmsnorm_kernel<TT, ADD, CH, BT>), dim3(rows), dim3(BT), 0, st, (St<TT>::S*)x, \
-                                          (const St<TT>::S*)r, (const St<TT>::S*)weight, (St<TT>::S*)y, hidden, eps, parts, n_parts, part_stride))
+                                          (const St<TT>::S*)r, (const St<TT>::S*)weight, (St<TT>::S*)y, hidden, eps, parts, n_parts, part_stride, sel, src_rows))
     // one 16-byte chunk per thread up to 512 threads (every load of the row in flight at once), then 2 / 4 / 8 chunks
     if (vecs <= 256) { RMS_LAUNCH(1, 256); } else if (vecs <= 512) { RMS_LAUNCH(1, 512); } else if (vecs <= 1024) { RMS_LAUNCH(2, 512); }
     else if (vecs <= 2048) { RMS_LAUNCH(4, 512); } else { RMS_LAUNCH(8, 512); }
@@ -318,6 +326,15 @@ extern "C" int lade_add_rmsnorm(void* x, const void* r, const void* weight, void
     if (rows == 0) return LADE_OK;
     hipStream_t st = (hipStream_t)stream;
     return launch_rmsnorm<true>(x, r, weight, y, rows, hidden, eps, dtype, st);
+}
+
+extern "C" int lade_add_rmsnorm_rows(const void* x, const void* r, const float* parts, int32_t n_parts, int64_t part_stride, const int32_t* sel,
+                                     const void* weight, void* y, int32_t n_sel, int32_t src_rows, int32_t hidden, float eps, int32_t dtype, void* stream) {
+    LADE_REQUIRE(x && sel && weight && y && n_sel >= 0 && src_rows > 0 && hidden > 0 && ((r != nullptr) != (parts != nullptr && n_parts > 0)), LADE_E_ARG,
+                 "lade_add_rmsnorm_rows: n_sel=%d src_rows=%d hidden=%d n_parts=%d (exactly one of r / parts)", n_sel, src_rows, hidden, n_parts);
+    LADE_REQUIRE(!parts || dtype != LADE_F32, LADE_E_DTYPE, "lade_add_rmsnorm_rows: split-K partials come from the 16-bit GEMM only");
+    if (n_sel == 0) return LADE_OK;
+    return launch_rmsnorm<true>((void*)x, r, weight, y, n_sel, hidden, eps, dtype, (hipStream_t)stream, parts, n_parts, (size_t)part_stride, sel, src_rows);
 }
 
 extern "C" int lade_silu_mul(const void* gu, void* out, int32_t rows, int32_t inter, int32_t layout, int32_t dtype, void* stream) {

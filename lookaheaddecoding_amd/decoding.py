@@ -439,9 +439,14 @@ class LookaheadDecoder:
         rows = 1 + g * gs if verify else 1
         if fused_T is not None:                              # temperature only: the kernels scale the logits themselves
             src, skip, temp = logits, n_inp, fused_T
-        else:                                                # top-k / top-p / HF warper objects: warped on the device by torch
-            picked = logits[0:1] if not verify else torch.cat([logits[0:1], logits[1 + n_inp:1 + n_inp + g * gs]])
-            src, skip, temp = warp(picked), 0, 1.0
+        else:
+            # top-k / top-p: one device launch over the out row and the candidate rows (lade_warp_rows); HF warper objects and
+            # vocabularies beyond that kernel: torch ops on the device
+            src = warp.warp_rows(logits, rows, n_inp) if hasattr(warp, "warp_rows") else None
+            if src is None:
+                picked = logits[0:1] if not verify else torch.cat([logits[0:1], logits[1 + n_inp:1 + n_inp + g * gs]])
+                src = warp(picked)
+            skip, temp = 0, 1.0
         max_hit_idx = 0
         if verify:
             ops.softmax_gather(src, rows, skip, st.guess, g, gs, max(G, 1), temp, buf["scal"], buf["stats"])

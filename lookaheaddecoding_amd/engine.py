@@ -417,13 +417,13 @@ class StepEngine:
             else:
                 torch.matmul(a, lw["wd"].t(), out=r)
                 r_parts = 0
-        if r_parts:                       # last layer's MLP output: fold the partials into r for the row-pruned tail
-            cabi.call("lade_splitk_reduce", cabi.ptr(part), cabi.ptr(r), r.stride(0), T, self.hidden, r_parts, cabi.dtype_code(r))
         if n_sel == 0:                                             # cache-filling chunk of a long prefill
             return None
-        xs = ops.gather_rows(x, sel_rows, rows=n_sel)
-        rs = ops.gather_rows(r, sel_rows, rows=n_sel)
-        hn = ops.add_rmsnorm(xs, rs, self.norm_w, self.eps)
+        # row-pruned tail in one launch: final residual add (the last MLP's split-K partials or r) + RMSNorm of the selected rows only
+        if r_parts:
+            hn = ops.add_rmsnorm_rows(x, sel_rows, n_sel, self.norm_w, self.eps, part=part, n_parts=r_parts)
+        else:
+            hn = ops.add_rmsnorm_rows(x, sel_rows, n_sel, self.norm_w, self.eps, r=r)
         return torch.matmul(hn, self.lm_head.t())
 
     # ---- prefill: plain causal rows over the growing cache ---------------------------------------------

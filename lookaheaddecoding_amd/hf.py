@@ -307,6 +307,27 @@ def jacobi_greedy_search_multilevel(self, input_ids, logits_processor=None, stop
     return _run(self, input_ids, False, None, stopping_criteria, eos_token_id, generation_config, streamer, chat)
 
 
+def _canonical_warper(warpers, T_cls, K_cls, P_cls):
+    """(temperature, top_k, top_p) when the list is what `generate()` builds - at most one warper of each kind, in the order
+    temperature, top-k, top-p, filtering with -inf and keeping one token - else None (the list is then applied as given)."""
+    order = {T_cls: 0, K_cls: 1, P_cls: 2}
+    kinds = [order[type(wp)] for wp in warpers]
+    if kinds != sorted(set(kinds)):
+        return None
+    t, k, p = 1.0, 0, 1.0
+    for wp in warpers:
+        if type(wp) is T_cls:
+            t = float(wp.temperature)
+        else:
+            if getattr(wp, "filter_value", -float("inf")) != -float("inf") or getattr(wp, "min_tokens_to_keep", 1) != 1:
+                return None
+            if type(wp) is K_cls:
+                k = int(wp.top_k)
+            else:
+                p = float(wp.top_p)
+    return t, k, p
+
+
 def jacobi_sample_multilevel(self, input_ids, logits_processor=None, stopping_criteria=None, logits_warper=None, max_length=None,
                              pad_token_id=None, eos_token_id=None, output_attentions=None, output_hidden_states=None, output_scores=None,
                              return_dict_in_generate=None, synced_gpus=False, streamer=None, chat=False, generation_config=None,
@@ -318,13 +339,12 @@ def jacobi_sample_multilevel(self, input_ids, logits_processor=None, stopping_cr
     for wp in warpers:
         assert type(wp) in (TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper), f"please set top_k=0.0 and top_p=1.0 {wp}"
 
-    if all(type(wp) is TemperatureLogitsWarper for wp in warpers):
-        # temperature only (BASELINE config 3): the scale is applied inside the device kernels (sampling.Warper.fused_temperature)
-        from .sampling import Warper
-        t = 1.0
-        for wp in warpers:
-            t *= float(wp.temperature)
-        warp = Warper(temperature=t)
+    from .sampling import Warper
+    canonical = _canonical_warper(warpers, TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper)
+    if canonical is not None:
+        # HF's own construction order (temperature -> top-k -> top-p, -inf filter, one token kept): the device kernels apply it -
+        # temperature alone inside the probability kernels (BASELINE config 3), with top-k / top-p as one lade_warp_rows launch
+        warp = Warper(*canonical)
     else:
         def warp(scores):
             for wp in warpers:

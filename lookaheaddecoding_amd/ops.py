@@ -187,6 +187,19 @@ def add_rmsnorm(x: torch.Tensor, r: torch.Tensor, w: torch.Tensor, eps: float, o
     return out
 
 
+def add_rmsnorm_rows(x: torch.Tensor, sel: torch.Tensor, n_sel: int, w: torch.Tensor, eps: float, *, r: Optional[torch.Tensor] = None,
+                     part: Optional[torch.Tensor] = None, n_parts: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[j] = rmsnorm(x[sel[j]] + res[sel[j]]), res = r or the sum of the first n_parts fp32 split-K partials in `part`
+    ([n_parts][rows][hidden]); x stays as it is.  The step's tail: only the rows whose logits are read."""
+    rows, hidden = x.shape
+    assert x.is_contiguous() and sel.dtype == torch.int32 and (r is None) != (part is None)
+    if out is None:
+        out = torch.empty(n_sel, hidden, dtype=x.dtype, device=x.device)
+    call("lade_add_rmsnorm_rows", ptr(x), ptr(r), ptr(part), n_parts if part is not None else 0, rows * hidden, ptr(sel), ptr(w), ptr(out), n_sel, rows, hidden,
+         eps, dtype_code(x))
+    return out[:n_sel]
+
+
 def silu_mul(gu: torch.Tensor, out: Optional[torch.Tensor] = None, layout: int = 0) -> torch.Tensor:
     """layout 0: gu rows = [gate | up]; 1: 16-row interleaved groups (the engine's fused gate/up order, see interleave_gate_up)"""
     assert gu.is_contiguous() and gu.shape[1] % 2 == 0
@@ -220,6 +233,25 @@ def softmax_rows(logits: torch.Tensor, temperature: float = 1.0, out: Optional[t
     assert probs.dtype == torch.float32 and probs.numel() >= logits.numel()
     call("lade_softmax_rows", ptr(logits), logits.stride(0), logits.shape[0], logits.shape[1], dtype_code(logits), float(temperature), ptr(probs))
     return probs
+
+
+WARP_MAX_V = 32768        # lade_warp_rows holds a row in one work-group's registers
+
+
+def warp_rows(logits: torch.Tensor, rows: int, skip: int, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Temperature -> top-k -> top-p (HF warper semantics) in one launch.  logits [>= rows + skip, V]: logical row 0 is physical row 0,
+    logical row r > 0 is physical row r + skip (out row + the candidate rows behind the window rows).  Returns fp32 [rows, V] with the
+    removed tokens at -inf."""
+    _dev(logits, "logits")
+    assert logits.dim() == 2 and logits.stride(1) == 1
+    V = logits.shape[1]
+    assert logits.shape[0] >= (rows + skip if rows > 1 else 1)
+    if out is None:
+        out = torch.empty(rows, V, dtype=torch.float32, device=logits.device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() >= rows * V
+    call("lade_warp_rows", ptr(logits), logits.stride(0), rows, V, dtype_code(logits), float(temperature), int(top_k), float(top_p), int(skip), ptr(out))
+    return out[:rows] if out.dim() == 2 else out
 
 
 def softmax_gather(logits: torch.Tensor, rows: int, skip: int, guess: torch.Tensor, g: int, gs: int, g_cap: int, temperature: float,

@@ -26,8 +26,10 @@ import torch
 
 class Warper:
     """Temperature -> top-k -> top-p on [rows, V] fp32 logits (same order and tie rules as HF's TemperatureLogitsWarper /
-    TopKLogitsWarper / TopPLogitsWarper); runs on whatever device the logits are on.  With top-k and top-p off the warp is a
-    plain scale, which the device kernels apply themselves (`fused_temperature`)."""
+    TopKLogitsWarper / TopPLogitsWarper).  With top-k and top-p off the warp is a plain scale, which the device kernels apply
+    themselves (`fused_temperature`); otherwise the sampling loop calls `warp_rows` - one HIP launch (lade_warp_rows: no sort, no
+    topk) - and `__call__` (torch ops on whatever device the logits are on) remains for vocabularies beyond that kernel and as the
+    plain statement of the semantics."""
 
     def __init__(self, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0):
         self.temperature, self.top_k, self.top_p = float(temperature), int(top_k or 0), float(top_p)
@@ -35,6 +37,14 @@ class Warper:
     @property
     def fused_temperature(self) -> Optional[float]:
         return self.temperature if (self.top_k <= 0 and self.top_p >= 1.0) else None
+
+    def warp_rows(self, logits: torch.Tensor, rows: int, skip: int) -> Optional[torch.Tensor]:
+        """The warp of logical rows 0 and 1 + skip .. (the out row and the candidate rows of a step's logits) as ONE device launch
+        (lade_warp_rows); None when the vocabulary exceeds what that kernel holds - the caller then uses __call__ (torch ops)."""
+        from . import ops
+        if not logits.is_cuda or logits.shape[-1] > ops.WARP_MAX_V:
+            return None
+        return ops.warp_rows(logits, rows, skip, self.temperature, self.top_k, self.top_p)
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         if self.temperature != 1.0:

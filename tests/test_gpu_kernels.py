@@ -540,3 +540,100 @@ def test_gate_up_gemm_with_swiglu_epilogue_and_interleaved_layout():
         o1 = torch.empty(M, inter, dtype=torch.bfloat16, device="cuda")
         ops.silu_mul_parts(parts, 2, M, inter, out=o1, layout=1)
         assert torch.allclose(o1.float(), two_kernel.float(), atol=2e-2, rtol=2e-2)
+
+
+# ---- logits warpers on the device (lade_warp_rows; lade/decoding.py:375-377) ------------------------------------------------------
+
+def _warp_reference(x, temperature, top_k, top_p):
+    """HF's Temperature / TopK / TopP warpers stated with a STABLE ascending sort (ties in token order - what torch's radix sort does on
+    the GPU the reference runs on); otherwise the oracle's warp_logits line by line."""
+    x = x.float()
+    if temperature != 1.0:
+        x = x / temperature
+    if top_k and 0 < top_k < x.shape[-1]:
+        kth = torch.topk(x, top_k)[0][..., -1, None]
+        x = x.masked_fill(x < kth, -float("inf"))
+    if top_p < 1.0:
+        sl, si = torch.sort(x, descending=False, stable=True)
+        cp = sl.softmax(dim=-1).cumsum(dim=-1)
+        rm = cp <= (1 - top_p)
+        rm[..., -1:] = False
+        x = x.masked_fill(rm.scatter(-1, si, rm), -float("inf"))
+    return x
+
+
+def test_warp_rows_equals_the_hf_warpers():
+    """Random fp32 rows (no ties): the device warp equals the oracle's warp_logits exactly - same kept set, same values - for temperature,
+    top-k, top-p and their combination at V = 32000 / 32016 / small vocabularies, with the out row + skipped window rows addressing."""
+    import lade_oracle as O
+    from lookaheaddecoding_amd import ops
+    g = torch.Generator().manual_seed(0)
+    for V in (32000, 32016, 257, 5):
+        n_phys, skip = 9, 3
+        logits = (torch.randn(n_phys, V, generator=g) * 3.0)
+        rows = n_phys - skip
+        pick = torch.cat([logits[0:1], logits[1 + skip:]])
+        for (temp, k, p) in ((1.0, 0, 0.9), (0.7, 50, 1.0), (0.8, 40, 0.95), (1.3, 0, 0.5), (1.0, 1, 1.0), (1.0, V + 5, 0.999), (0.6, 7, 0.3), (1.0, 0, 1e-6)):
+            ref = O.warp_logits(pick, temperature=temp, top_k=k, top_p=p)
+            out = ops.warp_rows(logits.cuda(), rows, skip, temp, k, p).cpu()
+            assert out.shape == ref.shape
+            same = torch.equal(torch.isinf(out), torch.isinf(ref)) and torch.equal(out[~torch.isinf(out)], ref[~torch.isinf(ref)])
+            assert same, (V, temp, k, p, int((torch.isinf(out) != torch.isinf(ref)).sum()))
+            assert (~torch.isinf(out)).sum(-1).min() >= 1                    # a token always survives
+
+
+def test_warp_rows_ties_follow_the_stable_order_and_dtypes():
+    """Logits with the granularity of a 16-bit model (thousands of equal values per row): the kept set must be the one a stable ascending
+    sort yields - within a tie group the lowest token ids go first - for bf16 / f16 / fp32 inputs; plus degenerate rows."""
+    from lookaheaddecoding_amd import ops
+    g = torch.Generator().manual_seed(1)
+    V = 32000
+    base = (torch.randn(6, V, generator=g) * 2.5)
+    for dt in (torch.bfloat16, torch.float16, torch.float32):
+        lg = base.to(torch.bfloat16).to(dt)                                  # bf16-granular values in every dtype
+        for (temp, k, p) in ((1.0, 0, 0.9), (0.8, 64, 0.9), (1.0, 200, 1.0), (0.5, 0, 0.6)):
+            ref = _warp_reference(lg, temp, k, p)
+            out = ops.warp_rows(lg.cuda(), 6, 0, temp, k, p).cpu()
+            bad = int((torch.isinf(out) != torch.isinf(ref)).sum())
+            assert bad == 0 and torch.equal(out[~torch.isinf(out)], ref[~torch.isinf(ref)]), (dt, temp, k, p, bad)
+    # all logits equal: top-p removes the lowest token ids until the mass left exceeds top_p; top-k keeps every tie
+    flat = torch.zeros(2, 1000)
+    out = ops.warp_rows(flat.cuda(), 2, 0, 1.0, 10, 1.0).cpu()
+    assert not torch.isinf(out).any()
+    out = ops.warp_rows(flat.cuda(), 2, 0, 1.0, 0, 0.25).cpu()
+    ref = _warp_reference(flat, 1.0, 0, 0.25)
+    assert abs(int(torch.isinf(out[0]).sum()) - int(torch.isinf(ref[0]).sum())) <= 1 and not torch.isinf(out[0, -1])
+    assert torch.isinf(out[0, :700]).all()                                   # the removed ones are the lowest ids
+    # a row that already holds -inf entries (a second warp, or a masked vocabulary)
+    holes = base[:1].clone()
+    holes[0, ::3] = -float("inf")
+    ref = _warp_reference(holes, 0.9, 30, 0.8)
+    out = ops.warp_rows(holes.cuda(), 1, 0, 0.9, 30, 0.8).cpu()
+    assert torch.equal(torch.isinf(out), torch.isinf(ref))
+
+
+def test_add_rmsnorm_rows_equals_gather_then_add_rmsnorm():
+    """The step's row-pruned tail in one launch (lade_add_rmsnorm_rows) against its unfused form: fold the split-K partials, gather the
+    selected rows of x and of the residual, add + RMSNorm - bit for bit, for a plain residual and for 1..5 partials, all dtypes."""
+    from lookaheaddecoding_amd import cabi, ops
+    torch.manual_seed(7)
+    for dt in (torch.bfloat16, torch.float16, torch.float32):
+        for hidden in (4096, 5120, 256):
+            T = 60
+            x = torch.randn(T, hidden, device="cuda").to(dt)
+            r = torch.randn(T, hidden, device="cuda").to(dt)
+            w = (1 + 0.1 * torch.randn(hidden, device="cuda")).to(dt)
+            sel = torch.tensor([0, 45, 46, 59, 59, 3, 17], dtype=torch.int32, device="cuda")
+            x0 = x.clone()
+            ref = ops.add_rmsnorm(ops.gather_rows(x, sel), ops.gather_rows(r, sel), w, 1e-5)
+            out = ops.add_rmsnorm_rows(x, sel, sel.numel(), w, 1e-5, r=r)
+            assert torch.equal(out, ref) and torch.equal(x, x0), (dt, hidden)
+            if dt == torch.float32:
+                continue
+            for n_parts in (1, 4, 5):
+                part = torch.randn(n_parts, T, hidden, device="cuda")
+                rr = torch.empty(T, hidden, dtype=dt, device="cuda")
+                cabi.call("lade_splitk_reduce", cabi.ptr(part), cabi.ptr(rr), rr.stride(0), T, hidden, n_parts, cabi.dtype_code(rr))
+                ref = ops.add_rmsnorm(ops.gather_rows(x, sel), ops.gather_rows(rr, sel), w, 1e-5)
+                out = ops.add_rmsnorm_rows(x, sel, sel.numel(), w, 1e-5, part=part, n_parts=n_parts)
+                assert torch.equal(out, ref), (dt, hidden, n_parts)
