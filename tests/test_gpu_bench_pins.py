@@ -73,9 +73,11 @@ def test_attention_pair_at_the_bench_launch_shapes_vs_dense_oracle(H, Hkv, T, P)
 
 def test_bf16_7b_width_lookahead_on_the_bench_prompt_length():
     """4 layers at the Llama-2-7B width, bf16, the bench's prompt (2048 random tokens, same generator seed), W=15 N=5 G=15, eager
-    and hipGraph: lookahead == plain greedy on the same engine (or both oracle-valid), and every emitted token within the margin
-    of DESIGN section 5 of the fp32 oracle run over the whole 2 k context on the CPU."""
-    from test_gpu_parity_shapes import _assert_cache_equals_plain_prefill, _oracle_margin
+    and hipGraph: lookahead == plain greedy on the same engine (or both oracle-valid); the engine's teacher-forced logits at the
+    2 k context are at least as close to the fp32 oracle as the reference's own bf16 arithmetic, and every emitted token stays
+    within 2.5 x that envelope - the oracle runs over the whole 2 k context on the CPU, in fp32 and in bf16."""
+    from test_gpu_parity_shapes import (_assert_cache_equals_plain_prefill, _assert_engine_logits_within_reference_envelope, _oracle_margin,
+                                        _reference_bf16_envelope)
     from lookaheaddecoding_amd.decoding import LookaheadDecoder
     from lookaheaddecoding_amd.engine import StepEngine
     cfg = make_config("llama2-7b", layers=4)
@@ -86,18 +88,21 @@ def test_bf16_7b_width_lookahead_on_the_bench_prompt_length():
     prompt = torch.randint(3, cfg["vocab"], (2048,), generator=torch.Generator().manual_seed(123)).tolist()
     n_new = 16
     plain = eng.plain_greedy(prompt, len(prompt) + n_new)
-    TOL, REL = 0.03, 0.0125
-    ok, worst_plain = _oracle_margin(cfg, w_cpu, torch.bfloat16, plain, len(prompt), tol=TOL, rel=REL)
-    assert ok, ("plain", worst_plain)
+    # the error budget is the reference's own bf16 arithmetic on these tokens, at the bench's context length
+    z, rms_ref, max_ref = _reference_bf16_envelope(cfg, w_cpu, plain, len(prompt))
+    _assert_engine_logits_within_reference_envelope(eng, z, rms_ref, max_ref, plain, len(prompt), "7B width, prompt 2048")
+    TOL = 2.5 * max_ref
+    ok, worst_plain = _oracle_margin(cfg, w_cpu, torch.bfloat16, plain, len(prompt), tol=TOL)
+    assert ok, ("plain", worst_plain, TOL)
     for use_graph in (False, True):
         dec = LookaheadDecoder(eng, 15, 5, 15, use_graph=use_graph)
         out = dec.greedy(prompt, len(prompt) + n_new, rng=random.Random(1), keep_trace=True)
         assert out.trace[-1]["P_before"] >= 2048 and eng.n_splits_for(60, out.trace[-1]["P_before"] + 60) >= 5
         if out.tokens != plain:
-            ok, worst = _oracle_margin(cfg, w_cpu, torch.bfloat16, out.tokens, len(prompt), tol=TOL, rel=REL)
-            assert ok, (use_graph, worst)
+            ok, worst = _oracle_margin(cfg, w_cpu, torch.bfloat16, out.tokens, len(prompt), tol=TOL)
+            assert ok, (use_graph, worst, TOL)
     _assert_cache_equals_plain_prefill(eng, dec.tokens, dec.P, ("7b-2k", True))
-    print(f"[7B width, prompt 2048] worst margin deficit of the plain stream beyond 1.25 % of the winner: {worst_plain:.4f}")
+    print(f"[7B width, prompt 2048] worst margin deficit of the plain stream {worst_plain:.4f} (allowed 2.5 x the reference's own bf16 error {max_ref:.4f})")
 
 
 # ---- the drop-in multi-GPU entry: config_lade(DIST_WORKERS=N) -> USE_LADE=1 model.generate() ------------------------------

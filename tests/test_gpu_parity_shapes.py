@@ -238,6 +238,39 @@ def _oracle_margin(cfg, w_cpu_f32, dtype, tokens, n_prompt, tol, rel=0.0):
     return True, worst
 
 
+def _reference_bf16_envelope(cfg, w_cpu_f32, tokens, n_prompt):
+    """What the REFERENCE's own 16-bit arithmetic does to these logits: the oracle run twice over the same tokens on the same
+    (bf16-rounded) weights - in fp32, and with every op output rounded to bf16 as the reference model computes in bf16
+    (OracleLlama(dtype=bfloat16): torch's bf16 ops, fp32 accumulation inside a matmul, one rounding per op).  Returns the fp32 logits
+    of the generated positions and the reference-bf16 error against them (rms, max).  This - not a number fitted to our own
+    measurements - is the error budget of the bf16 engine."""
+    wq = {k: v.to(torch.bfloat16).float() for k, v in w_cpu_f32.items()}
+    T = len(tokens) - 1
+    vis = np.tril(np.ones((T, T), dtype=bool))
+    out = []
+    for dt in (torch.float32, torch.bfloat16):
+        model = O.OracleLlama(cfg, wq, dtype=dt)
+        hid = model.forward(tokens[:-1], list(range(T)), vis, model.new_cache())
+        out.append(model.logits(hid[n_prompt - 1:]).float())
+    z, z_ref = out
+    e = z_ref - z
+    return z, e.pow(2).mean().sqrt().item(), e.abs().max().item()
+
+
+def _assert_engine_logits_within_reference_envelope(eng, z_fp32, rms_ref, max_ref, tokens, n_prompt, tag):
+    """teacher-forced engine logits of the generated positions (one causal pass over the same tokens) against the fp32 oracle: the
+    engine must be at least as close to fp32 as the reference's own bf16 arithmetic is - rms within 1.1 x, worst logit within 1.25 x
+    (fp32 scores, one rounding of the split-K sums and fp32 softmax statistics make it closer in practice; printed)."""
+    T = len(tokens) - 1
+    eng.reset()
+    logits, _ = eng.prefill(tokens[:-1], list(range(n_prompt - 1, T)))
+    e = logits.float().cpu() - z_fp32
+    rms, mx = e.pow(2).mean().sqrt().item(), e.abs().max().item()
+    print(f"[{tag}] logit error vs fp32 oracle: engine rms {rms:.4f} max {mx:.4f} | reference-in-bf16 rms {rms_ref:.4f} max {max_ref:.4f}")
+    assert rms <= 1.1 * rms_ref and mx <= 1.25 * max_ref, (tag, rms, rms_ref, mx, max_ref)
+    return mx
+
+
 def _kv_rows(eng, n):
     return [eng.k_cache(li)[:, :n].float().clone() for li in range(eng.L)], [eng.vt_cache(li)[:, :, :n].float().clone() for li in range(eng.L)]
 
@@ -263,12 +296,13 @@ FULL_WIDTH = [("llama2-7b", 4, 15, 5, 15), ("codellama-13b", 3, 20, 7, 20), ("ll
 @pytest.mark.parametrize("shape,layers,W,N,G", FULL_WIDTH)
 def test_full_width_real_weights_bf16_cold(shape, layers, W, N, G):
     """Untied random weights at the BASELINE widths (hidden / heads / GQA / vocab at full size, a few layers), bf16: attention,
-    GEMMs and glue all contribute to every logit.  The lookahead stream (eager and hipGraph) must be the plain greedy stream
-    of the same engine - or differ only where both are within the logit margin of the fp32 oracle - and every emitted token
-    must be within that margin: 0.03 + 1.25 % of the winning logit (about three bf16 ulps of it: logits of spread ~1.3 whose winners
-    reach 5-7.5, one ulp of the engine's logits there is 0.031).  The deficit depends on which GEMM shapes the per-box autotune
-    picks (they round differently): the largest measured on MI355X is 0.061 with the hand-written GEMMs (13B width) and 0.083 at a
-    winner of 7.4 with every projection on the library (LADE_GEMM=0, 70B width); it is printed."""
+    GEMMs and glue all contribute to every logit.  The error budget is the REFERENCE's own: the oracle run in bf16 the way the
+    reference model computes in bf16 (every op output rounded) deviates from its fp32 self by (rms_ref, max_ref) on these very
+    tokens.  Required: (1) the engine's teacher-forced logits are at least as close to fp32 as that (rms <= 1.1 x, max <= 1.25 x);
+    (2) every token the engine emits - plain decoding, lookahead eager and hipGraph - loses at most 2.5 x max_ref against the fp32
+    oracle's best token for its prefix: a token chosen by argmax over logits that are each within 1.25 x max_ref of fp32 can lose at
+    most twice that (error at the winner + error at the chosen token), in whatever kernel shape the step ran; (3) the lookahead
+    stream is the plain greedy stream, or both satisfy (2)."""
     from lookaheaddecoding_amd.decoding import LookaheadDecoder
     from lookaheaddecoding_amd.engine import StepEngine
     cfg = make_config(shape, layers=layers)
@@ -279,17 +313,19 @@ def test_full_width_real_weights_bf16_cold(shape, layers, W, N, G):
     prompt = torch.randint(3, cfg["vocab"], (96,), generator=torch.Generator().manual_seed(123)).tolist()
     n_new = 24
     plain = eng.plain_greedy(prompt, len(prompt) + n_new)
-    TOL, REL = 0.03, 0.0125
-    ok, worst_plain = _oracle_margin(cfg, w_cpu, torch.bfloat16, plain, len(prompt), tol=TOL, rel=REL)
-    assert ok, ("plain", shape, worst_plain)
+    z, rms_ref, max_ref = _reference_bf16_envelope(cfg, w_cpu, plain, len(prompt))
+    _assert_engine_logits_within_reference_envelope(eng, z, rms_ref, max_ref, plain, len(prompt), shape)
+    TOL = 2.5 * max_ref
+    ok, worst_plain = _oracle_margin(cfg, w_cpu, torch.bfloat16, plain, len(prompt), tol=TOL)
+    assert ok, ("plain", shape, worst_plain, TOL)
     for use_graph in (False, True):
         dec = LookaheadDecoder(eng, W, N, G, use_graph=use_graph)
         out = dec.greedy(prompt, len(prompt) + n_new, rng=random.Random(1))
         if out.tokens != plain:
-            ok, worst = _oracle_margin(cfg, w_cpu, torch.bfloat16, out.tokens, len(prompt), tol=TOL, rel=REL)
-            assert ok, (shape, use_graph, worst)
+            ok, worst = _oracle_margin(cfg, w_cpu, torch.bfloat16, out.tokens, len(prompt), tol=TOL)
+            assert ok, (shape, use_graph, worst, TOL)
         _assert_cache_equals_plain_prefill(eng, dec.tokens, dec.P, (shape, use_graph))
-    print(f"[{shape}] worst margin deficit of the plain stream beyond 1.25 % of the winner: {worst_plain:.4f}")
+    print(f"[{shape}] worst margin deficit of the plain stream {worst_plain:.4f} (allowed 2.5 x the reference's own bf16 error {max_ref:.4f} = {TOL:.4f})")
 
 
 @pytest.mark.parametrize("shape,layers,W,N,G", FULL_WIDTH)
