@@ -348,18 +348,20 @@ def worker(args):
     # ---- the attention launch pair timed IN the step: a few more steady steps, eager, with a hipEvent before the attention launch
     # and after the split merge of every layer (torch's current stream is the launch stream) ----
     in_situ = None
-    if rank == 0 and not use_lp and not args.no_extras:
+    if not args.no_extras:                           # every rank takes the steps (the step's collective needs them all), rank 0 records
         was_graph, dec.use_graph = dec.use_graph, False
         run.step()                                   # first eager step: one-off costs (autotune of a new row class ...)
         sync()
-        eng.attn_events, eng.attn_events_empty = [], []
+        if rank == 0:
+            eng.attn_events, eng.attn_events_empty = [], []
         te0 = time.perf_counter()
         for _ in range(4):
             run.step()
         sync()
         eager_ms = (time.perf_counter() - te0) / 4 * 1e3
         evs, eng.attn_events, dec.use_graph = eng.attn_events, None, was_graph
-        T_ref = int(round(avg_T))
+    if rank == 0 and not args.no_extras:
+        T_ref = int(round(avg_T)) if not use_lp else (evs[-1][2] if evs else 0)     # LP: the rank's own shard width
         evs = [e for e in evs if e[2] == T_ref] or evs           # launches of the steady shape only (a stray candidate changes T)
         durs = sorted(e0.elapsed_time(e1) * 1e3 for (e0, e1, _, _) in evs)
         # what an EMPTY bracket reads: every layer also records two events back to back right before the attention bracket
@@ -505,10 +507,10 @@ def worker(args):
         us = ops.time_attn(qkv, [eng.k_cache(li) for li in range(eng.L)], [eng.vt_cache(li) for li in range(eng.L)], mask,
                            H=cfg["heads"], Hkv=cfg["kv_heads"], d=cfg["head_dim"], n_splits=ns, reps=max(200, 8 * eng.L))
         us_iso, how = us, "isolated (no in-step measurement in this mode)"
-        if in_situ is not None and in_situ["T"] == T_k and in_situ["gpu_bound"]:
-            us, ns, how = in_situ["us"], in_situ["n_splits"], "hipEvents inside real decode steps"
-        elif graph_delta is not None and graph_delta["us"] > 0:
+        if graph_delta is not None and graph_delta["us"] > 0:
             us, how = graph_delta["us"], "hipGraph step time with / without the attention launches"
+        elif in_situ is not None and in_situ["T"] == T_k and in_situ["gpu_bound"]:
+            us, ns, how = in_situ["us"], in_situ["n_splits"], "hipEvents inside real decode steps, minus what an empty event bracket reads"
         alg = attn_algorithmic_bytes(cfg, T_k, P_end)
         flops = attn_useful_flops(cfg, T_k, P_end, W, N, g_mid) if not use_lp else 4 * cfg["head_dim"] * cfg["heads"] * T_k * P_end
         achieved = alg / (us * 1e-6) / 1e9
@@ -519,15 +521,15 @@ def worker(args):
                     "launch_us": round(us, 2), "launch_us_source": how, "algorithmic_bytes": alg, "T": T_k, "P": P_end,
                     "mfma": {"useful_flops": flops, "achieved_tflops": round(flops / (us * 1e-6) / 1e12, 1), "peak_tflops": 2500.0,
                              "frac": round(flops / (us * 1e-6) / 1e12 / 2500.0, 4),
-                             "note": "useful flops of the closed-form mask (SURVEY 8d) / the same launch time / dense bf16 MFMA peak; utilisation counters: profiles/r2_pmc/A7_mfma.csv (T=60), A7B_mfma.csv (T=120), A70_mfma.csv (70B LP shard)"},
+                             "note": "useful flops of the closed-form mask (SURVEY 8d) / the same launch time / dense bf16 MFMA peak; utilisation counters (SQ_VALU_MFMA_BUSY_CYCLES per launch, bench shapes c2 / c2 with candidates / c4 / c5): profiles/r3_pmc/attn_pmc_table.json"},
                     "launch_us_in_step": None if in_situ is None else {k: (round(v, 2) if isinstance(v, float) else v) for k, v in in_situ.items()},
                     "launch_us_graph_delta": None if graph_delta is None else {k: (round(v, 2) if isinstance(v, float) else v) for k, v in graph_delta.items()},
                     "launch_us_isolated": round(us_iso, 2),
-                    "note": "launch_us = one layer's launch pair (attention + split merge): bracketed by hipEvents on the launch stream INSIDE real decode "
-                            "steps (4 eager steady steps after the timed region, every layer; minus what an empty bracket - two events recorded back to back "
-                            "in the same place - reads, launch_us_in_step.empty_bracket_us; used when those steps are GPU bound), else (graph step "
-                            "time - graph step time without the attention launches) / layers, else isolated back-to-back launches cycling through the "
-                            "layers' K/V caches (every launch reads HBM)"}
+                    "note": "launch_us = one layer's launch pair (attention + split merge) inside real decode steps: (hipGraph step time - the same step with "
+                            "the attention launches left out) / layers when that was measured (single GPU); else the pair bracketed by hipEvents on the launch "
+                            "stream in 4 eager steady steps after the timed region, every layer, minus what an empty bracket - two events recorded back to back "
+                            "in the same place - reads (launch_us_in_step.empty_bracket_us; used when those steps are GPU bound); else isolated "
+                            "back-to-back launches cycling through the layers' K/V caches (every launch reads HBM)"}
         hot_l = hot_live() if extras else None
         hot = hot_regime() if extras else None          # last: it zeroes o_proj / down_proj
         cpu = None

@@ -415,11 +415,11 @@ class LPRunner:
 
 
 def greedy_lp(dec, prompt: Sequence[int], max_length: int, eos_token_id: Optional[int] = None,
-              rng: Optional[random.Random] = None, keep_trace: bool = False, backend=None, all_gather=None, on_step=None):
+              rng: Optional[random.Random] = None, keep_trace: bool = False, backend=None, all_gather=None, on_step=None, comm=None):
     """Greedy lookahead decoding under lookahead parallelism (jacobi_greedy_search_multilevel with
     DIST_WORKERS > 1, lade/decoding.py:697-1259)."""
     from .decoding import GenOut
-    run = LPRunner(dec, backend, all_gather)
+    run = LPRunner(dec, backend, all_gather, comm=comm)
     run.start(prompt, eos_token_id, rng)
     trace: List[dict] = []
     while True:

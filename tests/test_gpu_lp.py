@@ -223,3 +223,37 @@ def test_lp_graph_segments_single_rank_equals_single_gpu_runs():
     for run in runs[:4]:
         res = _lp_graph_threads(run, 1)
         assert res[0][0] == run["tokens"] and res[0][1] == run["steps"]
+
+
+def test_lp_loop_on_the_c_abi_communicator_without_torch_distributed(tmp_path):
+    """A caller without torch.distributed: RcclComm built over a byte channel (here a world of one rank, so none is needed), handed to the
+    package's lookahead-parallel loop - the step's all-gather, the window broadcast and the GEMM-table adoption all go through
+    lade_lp_allgather.  Run in a fresh process that never initialises torch.distributed; tokens == single-GPU decoding."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r"""
+import random, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from lookaheaddecoding_amd import parallel
+from lookaheaddecoding_amd.decoding import LookaheadDecoder
+from lookaheaddecoding_amd.engine import StepEngine
+from lookaheaddecoding_amd.weights import make_config, random_weights_numpy
+cfg = make_config("tiny-d128", max_pos=512)
+w = {k: torch.as_tensor(v) for k, v in random_weights_numpy(cfg, seed=2, std=0.08).items()}
+prompt = [1, 5, 9, 17, 33, 5, 9, 17, 44, 5, 9, 17, 33, 5, 9, 17]
+for dt in (torch.float32, torch.bfloat16):
+    eng = StepEngine(cfg, w, dtype=dt, max_seq=512, max_T=320)
+    single = LookaheadDecoder(eng, 7, 4, 7, pool_from_prompt=True).greedy(prompt, len(prompt) + 40, rng=random.Random(3))
+    comm = parallel.RcclComm(0, 1)
+    assert comm.count() == 1
+    dec = LookaheadDecoder(eng, 7, 4, 7, pool_from_prompt=True, lp=parallel.LPContext(rank=0, world=1, force=True), use_graph=True)
+    out = parallel.greedy_lp(dec, prompt, len(prompt) + 40, rng=random.Random(3), comm=comm)
+    comm.close()
+    assert out.tokens == single.tokens and out.steps == single.steps, (dt, out.tokens, single.tokens)
+assert not dist.is_initialized()
+print("OK")
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + "\n" + r.stderr[-3000:]

@@ -131,3 +131,39 @@ def test_resolve_drafts_equals_the_oracle_verify_loop():
             assert torch.allclose(mine, final["p"], atol=1e-6), trial
         if v.accepted:
             assert idx_ref == v.winner
+
+
+def test_file_channel_hands_rank0s_bytes_to_the_other_ranks(tmp_path):
+    """parallel.FileChannel: the byte channel a caller without torch.distributed gives RcclComm for the 128-byte unique id."""
+    import threading
+    from lookaheaddecoding_amd.parallel import FileChannel
+    blob = bytes(range(128))
+    got = {}
+
+    def rank(r):
+        ch = FileChannel(str(tmp_path / "chan"), r, timeout_s=20)
+        got[r] = ch(blob if r == 0 else None)
+
+    ts = [threading.Thread(target=rank, args=(r,)) for r in (2, 1, 0)]      # readers first: they poll until rank 0 has published
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert got == {0: blob, 1: blob, 2: blob}
+    import pytest
+    with pytest.raises(TimeoutError):
+        FileChannel(str(tmp_path / "empty"), 1, timeout_s=0.05)(None)
+
+
+def test_gemm_tune_table_round_trips_through_its_int32_block():
+    """rank 0's GEMM autotune decisions travel to the other ranks as a fixed int32 block through the step's own all-gather
+    (parallel.encode_tune_table / decode_tune_table): None (library GEMM) and every 5-tuple survive."""
+    from lookaheaddecoding_amd.parallel import decode_tune_table, encode_tune_table
+    names, classes = ("wqkv", "wo", "wgu", "wd"), (32, 64, 96, 128, 192, 256)
+    table = {f"{n}:{m}": None for n in names for m in classes}
+    table["wqkv:64"] = (1, 128, 5, 1, 0)
+    table["wgu:64"] = (2, 96, 1, 1, 1)
+    table["wd:256"] = (8, 128, 2, 4, 2)
+    words = encode_tune_table(table, names, classes)
+    assert len(words) == 6 * len(names) * len(classes) and all(isinstance(w, int) for w in words)
+    assert decode_tune_table(words, names, classes) == table
