@@ -108,7 +108,8 @@ def test_bf16_7b_width_lookahead_on_the_bench_prompt_length():
 # ---- the drop-in multi-GPU entry: config_lade(DIST_WORKERS=N) -> USE_LADE=1 model.generate() ------------------------------
 
 _WORKER = r"""
-import json, os, random, sys
+import faulthandler, json, os, random, sys
+faulthandler.dump_traceback_later(90, exit=True)      # a rank that hangs says where, and ends the test within minutes
 sys.path.insert(0, {root!r})
 import torch
 from transformers import LlamaConfig, LlamaForCausalLM
@@ -178,12 +179,22 @@ def _launch(world, backend, share_gpu, tmp_path):
     results = []
     for p in procs:
         try:
-            so, se = p.communicate(timeout=420)
+            so, se = p.communicate(timeout=240)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
             raise
-        assert p.returncode == 0, so[-1500:] + "\n" + se[-3000:]
+        if p.returncode != 0:                       # show every rank's tail: the rank that failed is rarely the one that is waited for first
+            tails = [so[-1500:] + "\n" + se[-4000:]]
+            for q in procs:
+                if q is not p:
+                    try:
+                        qo, qe = q.communicate(timeout=30)
+                    except subprocess.TimeoutExpired:
+                        q.kill()
+                        qo, qe = q.communicate()
+                    tails.append(qo[-1500:] + "\n" + qe[-4000:])
+            raise AssertionError("\n======== next rank ========\n".join(tails))
         results.append(_result_of(so))
     return sorted(results, key=lambda r: r["rank"])
 
@@ -216,7 +227,7 @@ def test_config_lade_dist_workers_generate_one_rccl_rank(tmp_path):
     port = _free_port()
     env = dict(os.environ, LOCAL_RANK="0", RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LADE_TEST_BACKEND="nccl",
                LADE_TEST_SHARE_GPU="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, str(script)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=420)
+    r = subprocess.run([sys.executable, str(script)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-1500:] + "\n" + r.stderr[-3000:]
     res = _result_of(r.stdout)
     assert res["dist_world"] == 1 and res["lp_decoder"] and res["same"], res
