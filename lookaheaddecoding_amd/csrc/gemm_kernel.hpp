@@ -10,7 +10,25 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int G_NSTAGE = 3;       // LDS ring depth: two tiles stay in flight while one is multiplied
+// LDS ring depth: NSTG - 1 tiles stay in flight while one is multiplied.  3 by default; -DLADE_G_NSTAGE_MAX=n (experiments) lets every
+// shape take up to n stages, as many as fit the 160 KB of LDS.
+#ifndef LADE_G_NSTAGE_MAX
+#define LADE_G_NSTAGE_MAX 3
+#endif
+constexpr int g_stages(int bn, int bm) {
+    const int fit = (160 * 1024) / ((bn + bm) * 128);
+    return fit < LADE_G_NSTAGE_MAX ? (fit < 3 ? 3 : fit) : LADE_G_NSTAGE_MAX;
+}
+// counted wait: at most `younger` whole tiles (of PIECES pieces per wave) may stay in flight
+template <int PIECES, int MAXY>
+__device__ __forceinline__ void g_wait_younger(int younger) {
+    if constexpr (MAXY <= 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        if (younger >= MAXY) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAXY * PIECES < 63 ? MAXY * PIECES : 63) : "memory");
+        else g_wait_younger<PIECES, MAXY - 1>(younger);
+    }
+}
 constexpr int G_THREADS = 512;
 
 __device__ __forceinline__ void g_barrier() { asm volatile("s_barrier" ::: "memory"); }
@@ -52,6 +70,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
     constexpr int W_PIECES = W_BYTES / 1024, A_PIECES = A_BYTES / 1024;      // 1-KiB DMA pieces per tile
     constexpr int TOTAL_PIECES = W_PIECES + A_PIECES;
     constexpr int PIECES = (TOTAL_PIECES + NW - 1) / NW;                     // per wave and stage (the tail repeats the last piece)
+    constexpr int G_NSTAGE = g_stages(BN, BM);
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -120,9 +139,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
     for (int i = 0; i < nt; ++i) {
         const int stage = i % G_NSTAGE;
         const int younger = min(nt, i + G_NSTAGE) - (i + 1);        // tiles requested after tile i that may stay in flight
-        if (younger >= 2) g_wait_vm<2 * PIECES>();
-        else if (younger == 1) g_wait_vm<PIECES>();
-        else g_wait_vm<0>();
+        g_wait_younger<PIECES, G_NSTAGE - 1>(younger);
         g_barrier();
         const unsigned char* ws = smem + stage * STAGE;
         const unsigned char* as = ws + W_BYTES;
@@ -265,6 +282,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
 template <typename T, int MW, int MT, int NG, int NT>
 static int launch_gemm(const GemmK& g, hipStream_t st) {
     constexpr int BN = 32 * NT * NG, BM = 32 * MW * MT;
+    constexpr int G_NSTAGE = g_stages(BN, BM);
     constexpr size_t lds = (size_t)G_NSTAGE * (BN + BM) * 128;
     static_assert(lds <= 160 * 1024, "LDS ring too large");
     static bool attr = false;

@@ -201,8 +201,18 @@ def _launch(world, backend, share_gpu, tmp_path):
 
 def test_config_lade_dist_workers_generate_two_gloo_ranks_on_one_gpu(tmp_path):
     """DIST_WORKERS=2 through the public surface, two processes: `_join_lookahead_parallel_group` joins the group, `hf._run`
-    builds the lookahead-parallel decoder, `generate()` returns the single-GPU greedy stream on BOTH ranks, rank 0 logs."""
-    res = _launch(2, "gloo", True, tmp_path)
+    builds the lookahead-parallel decoder, `generate()` returns the single-GPU greedy stream on BOTH ranks, rank 0 logs.
+    Two ranks time-sharing ONE GPU over gloo is a configuration only this test uses (RCCL refuses it, a real run has a GPU per
+    rank).  Once in 11 runs a rank was seen to stall at start-up right after another process had torn down an RCCL communicator
+    on the same GPU; the workers arm a faulthandler watchdog (they exit with a stack dump after 90 s), and a run that ended that way
+    - and only that way - is repeated once."""
+    try:
+        res = _launch(2, "gloo", True, tmp_path)
+    except (AssertionError, subprocess.TimeoutExpired) as e:
+        if "Timeout (0:01:30)!" not in str(e) and not isinstance(e, subprocess.TimeoutExpired):
+            raise
+        print("watchdog fired on the first attempt:\n", str(e)[-3000:])
+        res = _launch(2, "gloo", True, tmp_path)
     assert [r["rank"] for r in res] == [0, 1]
     for r in res:
         assert r["distributed"] and r["dist_world"] == 2 and r["lp_decoder"], r
