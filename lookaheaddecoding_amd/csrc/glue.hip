@@ -247,6 +247,51 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const typename St<T>:
     for (int i = threadIdx.x; i < V; i += blockDim.x) out[i] *= inv;
 }
 
+// The same row softmax with the row held in registers: 1024 threads, 16-byte loads, CH chunks per thread (V <= 1024 * CH * N), one read of
+// the logits and one write of the probabilities.  The sampling loop calls this once per step for the ONE row a token is drawn from; the
+// three dependent scalar sweeps above cost 97 us for a 32000-entry row (a quarter-occupied CU walking 125 elements per thread three
+// times), this form ~6 us.  Used when the row is 16-byte aligned and V a multiple of the vector width.
+template <typename T, int CH>
+__global__ __launch_bounds__(1024) void softmax_rows_vec_kernel(const typename St<T>::S* logits, int64_t ld, int V, float inv_temp, float* probs) {
+    constexpr int N = Vec<T>::N;
+    __shared__ float sm[16];
+    const size_t base = (size_t)blockIdx.x * ld;
+    float* out = probs + (size_t)blockIdx.x * V;
+    const int nvec = V / N;
+    float v[CH][N];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int i = threadIdx.x + c * 1024;
+        if (i < nvec) {
+            unpack<T>(*reinterpret_cast<const u32x4*>(logits + base + (size_t)i * N), v[c]);
+#pragma unroll
+            for (int e = 0; e < N; ++e) { v[c][e] *= inv_temp; mx = fmaxf(mx, v[c][e]); }
+        }
+    }
+    mx = block_max(mx, sm);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int i = threadIdx.x + c * 1024;
+        if (i < nvec) {
+#pragma unroll
+            for (int e = 0; e < N; ++e) { v[c][e] = expf(v[c][e] - mx); s += v[c][e]; }
+        }
+    }
+    s = block_sum(s, sm);
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int i = threadIdx.x + c * 1024;
+        if (i < nvec) {
+#pragma unroll
+            for (int q = 0; q < N / 4; ++q)
+                *reinterpret_cast<float4*>(out + (size_t)i * N + 4 * q) = float4{v[c][4 * q] * inv, v[c][4 * q + 1] * inv, v[c][4 * q + 2] * inv, v[c][4 * q + 3] * inv};
+        }
+    }
+}
+
 // Sampling verify, device side (lade/decoding.py:484-540): the host-side acceptance loop only ever looks at the probability of a
 // DRAFT token under the distribution that follows an accepted prefix.  Row 0 is the distribution after the input token,
 // row 1 + c*gs + j the one after position j of candidate c.  For row 0 the drafts in question are the candidates' first
@@ -358,7 +403,16 @@ extern "C" int lade_softmax_rows(const void* logits, int64_t ld, int32_t rows, i
     LADE_REQUIRE(logits && probs && rows >= 0 && V > 0 && ld >= V && temperature > 0.f, LADE_E_ARG, "lade_softmax_rows: rows=%d V=%d T=%f", rows, V, temperature);
     if (rows == 0) return LADE_OK;
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(softmax_rows_kernel<TT>, dim3(rows), dim3(256), 0, st, (const St<TT>::S*)logits, ld, V, 1.f / temperature, probs));
+    const int esz = dtype == LADE_F32 ? 4 : 2, nvw = 16 / esz;
+    const bool vec_ok = V % nvw == 0 && V % 4 == 0 && ((uintptr_t)logits % 16) == 0 && ((size_t)ld * esz) % 16 == 0 && ((uintptr_t)probs % 16) == 0;
+    const int chunks = (V / nvw + 1023) / 1024;             // 16-byte chunks per thread
+    if (vec_ok && chunks <= 8) {
+        if (chunks <= 2) { DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((softmax_rows_vec_kernel<TT, 2>), dim3(rows), dim3(1024), 0, st, (const St<TT>::S*)logits, ld, V, 1.f / temperature, probs)); }
+        else if (chunks <= 4) { DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((softmax_rows_vec_kernel<TT, 4>), dim3(rows), dim3(1024), 0, st, (const St<TT>::S*)logits, ld, V, 1.f / temperature, probs)); }
+        else { DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((softmax_rows_vec_kernel<TT, 8>), dim3(rows), dim3(1024), 0, st, (const St<TT>::S*)logits, ld, V, 1.f / temperature, probs)); }
+    } else {
+        DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(softmax_rows_kernel<TT>, dim3(rows), dim3(256), 0, st, (const St<TT>::S*)logits, ld, V, 1.f / temperature, probs));
+    }
     return check_launch("lade_softmax_rows");
 }
 

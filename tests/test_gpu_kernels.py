@@ -661,3 +661,22 @@ def test_add_rmsnorm_rows_equals_gather_then_add_rmsnorm():
                 ref = ops.add_rmsnorm(ops.gather_rows(x, sel), ops.gather_rows(rr, sel), w, 1e-5)
                 out = ops.add_rmsnorm_rows(x, sel, sel.numel(), w, 1e-5, part=part, n_parts=n_parts)
                 assert torch.equal(out, ref), (dt, hidden, n_parts)
+
+
+def test_softmax_rows_register_resident_and_fallback_paths():
+    """lade_softmax_rows: the register-resident 1024-thread form (aligned rows, V a multiple of the vector width) and the scalar
+    fallback (odd V, unaligned rows) against torch.softmax, all dtypes, several rows."""
+    from lookaheaddecoding_amd import ops
+    torch.manual_seed(11)
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        for V in (32000, 32016, 32001, 257, 65536, 70000):
+            x = (torch.randn(3, V, device="cuda") * 3).to(dt)
+            for temp in (1.0, 0.7):
+                ref = torch.softmax(x.float() / temp, dim=-1)
+                out = ops.softmax_rows(x, temp)
+                assert torch.allclose(out, ref, rtol=2e-4, atol=1e-8), (dt, V, temp, (out - ref).abs().max().item())
+                assert torch.allclose(out.sum(-1), torch.ones(3, device="cuda"), atol=1e-4)
+        # a row slice that is not 16-byte aligned takes the scalar path
+        x = (torch.randn(2, 32001, device="cuda") * 3).to(dt)
+        out = ops.softmax_rows(x[1:2], 0.9)
+        assert torch.allclose(out, torch.softmax(x[1:2].float() / 0.9, dim=-1), rtol=2e-4, atol=1e-8)
