@@ -433,13 +433,24 @@ def worker(args):
     # feed the logits (tests/test_gpu_parity_shapes.py: test_full_width_real_weights_bf16_with_accepted_ngrams).  The lookahead stream is
     # checked against plain greedy decoding on the same engine.
     def hot_live():
-        eng.embed.mul_(50.0)
-        saved_head, eng.lm_head = eng.lm_head, eng.embed
+        # the embedding scale that makes a random model copy-biased grows with its depth and width: powers of two (exact in bf16, exactly
+        # undone afterwards) are tried in turn until the model accepts n-grams (S >= 2) in a short trial
         live_prompt = [(7 * i) % 50 + 3 for i in range(args.prompt_len)]
-        ld = LookaheadDecoder(eng, W, N, G, pool_from_prompt=True, use_graph=not args.no_graph)
-        ld.start(live_prompt, rng=random.Random(1))
-        for _ in range(N - 1 + args.warmup):
-            ld.step()
+        saved_head, eng.lm_head = eng.lm_head, eng.embed
+        applied, chosen, ld = 1.0, None, None
+        for scale in (64.0, 128.0, 256.0, 512.0):
+            eng.embed.mul_(scale / applied)
+            applied = scale
+            ld = LookaheadDecoder(eng, W, N, G, pool_from_prompt=True, use_graph=not args.no_graph)
+            ld.start(live_prompt, rng=random.Random(1))
+            for _ in range(N - 1 + args.warmup):
+                ld.step()
+            t0_tok = len(ld.tokens)
+            for _ in range(8):
+                ld.step()
+            chosen = scale
+            if (len(ld.tokens) - t0_tok) / 8 >= 2.0:
+                break
         sync()
         tok_l = len(ld.tokens)
         tl0 = time.perf_counter()
@@ -452,12 +463,12 @@ def worker(args):
         n_same = next((i for i, (x, y) in enumerate(zip(gen_all, plain_ref)) if x != y), n_chk)
         out_l = {"value": round((len(ld.tokens) - tok_l) / tl, 2), "unit": "tokens/s", "step_compression": round((len(ld.tokens) - tok_l) / args.steps, 3),
                  "ms_per_step": round(tl / args.steps * 1e3, 3), "tokens_per_step_T": round(sum(i["T"] for i in li) / len(li), 1),
-                 "equals_plain_greedy_for": f"{n_same} of the first {n_chk} generated tokens",
-                 "how": "live weights: embedding x50 tied to lm_head (copy-biased random model, attention / MLP / every projection feed the logits), periodic "
-                        "prompt (period 50), POOL_FROM_PROMPT=1; S is the model's own acceptance rate; stream compared with plain greedy on the same engine "
-                        "(bf16: the two may part where two logits tie within rounding)"}
+                 "embedding_scale": chosen, "equals_plain_greedy_for": f"{n_same} of the first {n_chk} generated tokens",
+                 "how": f"live weights: embedding x{chosen:g} tied to lm_head (copy-biased random model, attention / MLP / every projection feed the logits; the "
+                        "scale is the first power of two from 64 at which the model accepts n-grams), periodic prompt (period 50), POOL_FROM_PROMPT=1; S is the "
+                        "model's own acceptance rate; stream compared with plain greedy on the same engine (bf16: the two may part where two logits tie within rounding)"}
         eng.lm_head = saved_head
-        eng.embed.mul_(1.0 / 50.0)
+        eng.embed.mul_(1.0 / applied)
         return out_l
 
     def hot_regime():

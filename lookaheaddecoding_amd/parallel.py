@@ -247,8 +247,33 @@ class HipLPBackend:
         n_inp = ls[-1]
         call("lade_lp_pack", am, am + 4, n_inp, am + 4 * (1 + n_inp), gcap, gs, st.wcap, ptr(self.rec), self.rw, ptr(st.ctl), lp.rank, lp.R)
 
+    def _capture_segment(self, P: int, n_input: int, ls: Sequence[int], c0: int, c1: int, gcap: int):
+        d, st, e = self.dec, self.dec.st, self.dec.e
+        gs = d.gs
+        T = n_input + sum(ls) + gcap * gs
+        rows = [n_input - 1] + list(range(T - gcap * gs - ls[-1], T))
+        sel = torch.tensor(rows, dtype=torch.int32, device=self.device)
+        n_splits = e.n_splits_for(T, max(P + T, 1024))
+        state = (st.ctl, st.window, st.pool_cnt, st.pool_tok, st.guess, st.tail)
+        with HipLPBackend._capture_lock:           # one capture at a time per process (ranks may be threads in the tests)
+            saved = [t.clone() for t in state]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._segment_body(n_input, ls, c0, c1, gcap, sel, n_splits)       # warm-up: library handles, autotune
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            for t, sv in zip(state, saved):
+                t.copy_(sv)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self._segment_body(n_input, ls, c0, c1, gcap, sel, n_splits)
+        return (g, sel, n_splits)
+
     def local_step_graph(self, P: int, n_input: int, level_lens: Sequence[int], c0: int, c1: int, g_local: int):
-        """Replays (capturing on first use) the segment for this step's shape; returns the record tensor."""
+        """Replays (capturing on first use) the segment for this step's shape; returns the record tensor.  The first steady step
+        (one input token) captures the segments of ALL candidate buckets at once, like the single-GPU decoder does: the GEMM autotune
+        of a wider row class then happens during warm-up, not in the step that first meets a candidate."""
         d, st, e = self.dec, self.dec.st, self.dec.e
         gs = d.gs
         ls = shard_level_sizes(level_lens, c0, c1)
@@ -261,24 +286,11 @@ class HipLPBackend:
         want_splits = e.n_splits_for(T, P + T)
         ent = graphs.get(key)
         if ent is None or abs(want_splits - ent[2]) >= 2:
-            rows = [n_input - 1] + list(range(T - gcap * gs - ls[-1], T))
-            sel = torch.tensor(rows, dtype=torch.int32, device=self.device)
-            n_splits = e.n_splits_for(T, max(P + T, 1024))
-            state = (st.ctl, st.window, st.pool_cnt, st.pool_tok, st.guess, st.tail)
-            with HipLPBackend._capture_lock:           # one capture at a time per process (ranks may be threads in the tests)
-                saved = [t.clone() for t in state]
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    self._segment_body(n_input, ls, c0, c1, gcap, sel, n_splits)       # warm-up: library handles, autotune
-                torch.cuda.current_stream().wait_stream(side)
-                torch.cuda.synchronize()
-                for t, sv in zip(state, saved):
-                    t.copy_(sv)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    self._segment_body(n_input, ls, c0, c1, gcap, sel, n_splits)
-            ent = graphs[key] = (g, sel, n_splits)
+            ent = graphs[key] = self._capture_segment(P, n_input, ls, c0, c1, gcap)
+            if n_input == 1:
+                for b in self._local_buckets():
+                    if (1, b, e.generation) not in graphs and P + 1 + sum(ls) + b * gs <= e.S_max:
+                        graphs[(1, b, e.generation)] = self._capture_segment(P, 1, ls, c0, c1, b)
         ent[0].replay()
         return self.rec
 
