@@ -20,6 +20,8 @@
 // V is kept TRANSPOSED in HBM ([Hkv][d][S_max]) so its fragments are contiguous along keys.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace lade {
@@ -546,70 +548,136 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
     }
     dbg_stamp(a, 3);
 
-    // ---- merge the key parts: wave (rg, kq > 0) hands its state to wave (rg, 0), lane to lane ----
+    // ---- merge the key parts ----
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     wg_barrier();                      // ring no longer read or written: reuse it
-    constexpr int EX_F4 = DBLK * 4 + 1;                // float4 slots per lane: O^T (16*DBLK floats) + (m, l, -, -)
-    static_assert((size_t)(KQ - 1) * RG * EX_F4 * 64 * 16 <= (size_t)NSTG * STAGE_BYTES, "merge slots must fit in the ring");
-    float4* ex_all = reinterpret_cast<float4*>(smem);
-    if (kq > 0) {
-        float4* ex = ex_all + (size_t)((kq - 1) * RG + rg) * EX_F4 * 64;
-#pragma unroll
-        for (int db = 0; db < DBLK; ++db)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4)
-                ex[(db * 4 + g4) * 64 + lane] = float4{oacc[db][4 * g4], oacc[db][4 * g4 + 1], oacc[db][4 * g4 + 2], oacc[db][4 * g4 + 3]};
-        ex[(DBLK * 4) * 64 + lane] = float4{m_run, l_run, 0.f, 0.f};
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    wg_barrier();
     constexpr int RS = 2 * D + 16;                     // staging row stride (bytes), 16-B aligned
-    // staging rows of row group rg: the merge slot of (kq = 1, rg), which only wave (rg, 0) reads (LDS operations of one wave
-    // execute in order, so its staging writes cannot overtake its own merge reads); without key parts to merge, the ring head
-    unsigned char* stg_base = reinterpret_cast<unsigned char*>(ex_all);
-    constexpr size_t STG_STRIDE = (size_t)EX_F4 * 64 * 16;
-    static_assert(32 * RS <= STG_STRIDE, "a row group's staging rows fit in its merge slot");
-    if (kq == 0) {
+    unsigned char* stg_base;                           // normalised rows of the block in the model dtype, 32 rows per row group
+    size_t stg_stride;
+    if constexpr (KQ == 2) {
+        // Two key parts (the default shape): the two waves of a row group SWAP halves of O^T - wave (rg, kq) keeps the d-blocks
+        // [kq*HALF, kq*HALF + HALF) and hands the other half plus its (m, l) to its partner - so that each merges, normalises, packs and
+        // stages half of the columns.  All fragment reads of the merge are requested before the first use (the compiler had chained them
+        // one LDS latency after the other: 16 x ~100 cycles on the critical path of every launch).
+        constexpr int HALF = DBLK / 2;
+        constexpr int SX_F4 = HALF * 4 + 1;            // float4 rows per lane of a hand-over slot: HALF d-blocks + (m, l, -, -)
+        constexpr size_t SLOT = (size_t)SX_F4 * 64 * 16;
+        constexpr size_t STG_OFF = SLOT * RG * 2;
+        static_assert(STG_OFF + (size_t)RG * 32 * RS <= (size_t)NSTG * STAGE_BYTES + Q_BYTES, "hand-over slots + staging rows must fit in the ring + Q tile");
+        stg_base = smem + STG_OFF;
+        stg_stride = (size_t)32 * RS;
+        // kq is wave uniform: the two roles are two straight-line instantiations (a run-time select between register arrays would be
+        // compiled into a scratch-memory round trip)
+        auto swap_merge = [&](auto first_part) {
+            constexpr bool P0 = decltype(first_part)::value;          // this wave holds key part 0 and keeps the LOWER d-blocks
+            constexpr int KEEP = P0 ? 0 : HALF, SEND = P0 ? HALF : 0;
+            float4* mine = reinterpret_cast<float4*>(smem + SLOT * (rg * 2 + (P0 ? 0 : 1)));
+            const float4* theirs = reinterpret_cast<const float4*>(smem + SLOT * (rg * 2 + (P0 ? 1 : 0)));
 #pragma unroll
-        for (int pq = 1; pq < KQ; ++pq) {
-            const float4* ex = ex_all + (size_t)((pq - 1) * RG + rg) * EX_F4 * 64;
-            const float4 ml1 = ex[(DBLK * 4) * 64 + lane];
-            const float mm = fmaxf(m_run, ml1.x);
-            const float a0 = __builtin_amdgcn_exp2f(m_run - mm), a1 = __builtin_amdgcn_exp2f(ml1.x - mm);
+            for (int h = 0; h < HALF; ++h)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+                    mine[(h * 4 + g4) * 64 + lane] = float4{oacc[SEND + h][4 * g4], oacc[SEND + h][4 * g4 + 1], oacc[SEND + h][4 * g4 + 2], oacc[SEND + h][4 * g4 + 3]};
+            mine[(HALF * 4) * 64 + lane] = float4{m_run, l_run, 0.f, 0.f};
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wg_barrier();
+            float4 in[HALF * 4];
+            const float4 mlo = theirs[(HALF * 4) * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < HALF * 4; ++j) in[j] = theirs[j * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);             // every read is in flight before the first one is consumed
+            // the same expression in both waves, always in key-part order (part 0, part 1): identical m and l on both sides
+            const float m0 = P0 ? m_run : mlo.x, m1 = P0 ? mlo.x : m_run;
+            const float l0 = P0 ? l_run : mlo.y, l1 = P0 ? mlo.y : l_run;
+            const float mm = fmaxf(m0, m1);
+            const float a0 = __builtin_amdgcn_exp2f(m0 - mm), a1 = __builtin_amdgcn_exp2f(m1 - mm);
+            float lsum = __builtin_fmaf(l0, a0, l1 * a1);
+            dbg_stamp(a, 4);
+            lsum += __shfl_xor(lsum, 32);
+            const float inv = lsum > 0.f ? __builtin_amdgcn_rcpf(lsum) : 0.f;      // 1 ulp; the result is rounded to 16 bits
+            const float s_own = (P0 ? a0 : a1) * inv, s_oth = (P0 ? a1 : a0) * inv;
+            unsigned char* stg = stg_base + (size_t)rg * stg_stride;
+#pragma unroll
+            for (int h = 0; h < HALF; ++h)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float4 o1 = in[h * 4 + g4];
+                    u32x2 w;
+                    w[0] = pack2<T>(__builtin_fmaf(oacc[KEEP + h][4 * g4 + 0], s_own, o1.x * s_oth), __builtin_fmaf(oacc[KEEP + h][4 * g4 + 1], s_own, o1.y * s_oth));
+                    w[1] = pack2<T>(__builtin_fmaf(oacc[KEEP + h][4 * g4 + 2], s_own, o1.z * s_oth), __builtin_fmaf(oacc[KEEP + h][4 * g4 + 3], s_own, o1.w * s_oth));
+                    *reinterpret_cast<u32x2*>(stg + ql * RS + ((KEEP + h) * 32 + 8 * g4 + 4 * hi) * 2) = w;
+                }
+            if (P0 && a.n_splits > 1 && valid && hi == 0) {
+                const size_t prow = ((size_t)sp * a.H + qh) * m.T + t;
+                *reinterpret_cast<float2*>(a.part_ml + prow * 2) = float2{mm, lsum};
+            }
+        };
+        if (kq == 0) swap_merge(std::true_type{});
+        else swap_merge(std::false_type{});
+    } else {
+        // more than two key parts (the 64- and 32-row shapes): wave (rg, kq > 0) hands its state to wave (rg, 0), lane to lane
+        constexpr int EX_F4 = DBLK * 4 + 1;            // float4 slots per lane: O^T (16*DBLK floats) + (m, l, -, -)
+        static_assert((size_t)(KQ - 1) * RG * EX_F4 * 64 * 16 <= (size_t)NSTG * STAGE_BYTES, "merge slots must fit in the ring");
+        float4* ex_all = reinterpret_cast<float4*>(smem);
+        if (kq > 0) {
+            float4* ex = ex_all + (size_t)((kq - 1) * RG + rg) * EX_F4 * 64;
+#pragma unroll
+            for (int db = 0; db < DBLK; ++db)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+                    ex[(db * 4 + g4) * 64 + lane] = float4{oacc[db][4 * g4], oacc[db][4 * g4 + 1], oacc[db][4 * g4 + 2], oacc[db][4 * g4 + 3]};
+            ex[(DBLK * 4) * 64 + lane] = float4{m_run, l_run, 0.f, 0.f};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wg_barrier();
+        // staging rows of row group rg: the merge slot of (kq = 1, rg), which only wave (rg, 0) reads (LDS operations of one wave
+        // execute in order, so its staging writes cannot overtake its own merge reads)
+        stg_base = reinterpret_cast<unsigned char*>(ex_all);
+        stg_stride = (size_t)EX_F4 * 64 * 16;
+        static_assert(32 * RS <= (size_t)EX_F4 * 64 * 16, "a row group's staging rows fit in its merge slot");
+        if (kq == 0) {
+#pragma unroll
+            for (int pq = 1; pq < KQ; ++pq) {
+                const float4* ex = ex_all + (size_t)((pq - 1) * RG + rg) * EX_F4 * 64;
+                const float4 ml1 = ex[(DBLK * 4) * 64 + lane];
+                const float mm = fmaxf(m_run, ml1.x);
+                const float a0 = __builtin_amdgcn_exp2f(m_run - mm), a1 = __builtin_amdgcn_exp2f(ml1.x - mm);
+#pragma unroll
+                for (int db = 0; db < DBLK; ++db)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const float4 o1 = ex[(db * 4 + g4) * 64 + lane];
+                        oacc[db][4 * g4 + 0] = oacc[db][4 * g4 + 0] * a0 + o1.x * a1;
+                        oacc[db][4 * g4 + 1] = oacc[db][4 * g4 + 1] * a0 + o1.y * a1;
+                        oacc[db][4 * g4 + 2] = oacc[db][4 * g4 + 2] * a0 + o1.z * a1;
+                        oacc[db][4 * g4 + 3] = oacc[db][4 * g4 + 3] * a0 + o1.w * a1;
+                    }
+                l_run = l_run * a0 + ml1.y * a1;
+                m_run = mm;
+            }
+            // ---- normalise, transpose through LDS ----
+            dbg_stamp(a, 4);
+            l_run += __shfl_xor(l_run, 32);
+            unsigned char* stg = stg_base + (size_t)rg * stg_stride;
+            const float inv = l_run > 0.f ? __builtin_amdgcn_rcpf(l_run) : 0.f;      // 1 ulp; the result is rounded to 16 bits
 #pragma unroll
             for (int db = 0; db < DBLK; ++db)
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    const float4 o1 = ex[(db * 4 + g4) * 64 + lane];
-                    oacc[db][4 * g4 + 0] = oacc[db][4 * g4 + 0] * a0 + o1.x * a1;
-                    oacc[db][4 * g4 + 1] = oacc[db][4 * g4 + 1] * a0 + o1.y * a1;
-                    oacc[db][4 * g4 + 2] = oacc[db][4 * g4 + 2] * a0 + o1.z * a1;
-                    oacc[db][4 * g4 + 3] = oacc[db][4 * g4 + 3] * a0 + o1.w * a1;
+                    u32x2 w;
+                    w[0] = pack2<T>(oacc[db][4 * g4 + 0] * inv, oacc[db][4 * g4 + 1] * inv);
+                    w[1] = pack2<T>(oacc[db][4 * g4 + 2] * inv, oacc[db][4 * g4 + 3] * inv);
+                    *reinterpret_cast<u32x2*>(stg + ql * RS + (db * 32 + 8 * g4 + 4 * hi) * 2) = w;
                 }
-            l_run = l_run * a0 + ml1.y * a1;
-            m_run = mm;
-        }
-        // ---- normalise, transpose through LDS ----
-        dbg_stamp(a, 4);
-        l_run += __shfl_xor(l_run, 32);
-        unsigned char* stg = stg_base + (size_t)rg * STG_STRIDE;
-        const float inv = l_run > 0.f ? __builtin_amdgcn_rcpf(l_run) : 0.f;      // 1 ulp; the result is rounded to 16 bits
-#pragma unroll
-        for (int db = 0; db < DBLK; ++db)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                u32x2 w;
-                w[0] = pack2<T>(oacc[db][4 * g4 + 0] * inv, oacc[db][4 * g4 + 1] * inv);
-                w[1] = pack2<T>(oacc[db][4 * g4 + 2] * inv, oacc[db][4 * g4 + 3] * inv);
-                *reinterpret_cast<u32x2*>(stg + ql * RS + (db * 32 + 8 * g4 + 4 * hi) * 2) = w;
+            if (a.n_splits > 1 && valid && hi == 0) {
+                const size_t prow = ((size_t)sp * a.H + qh) * m.T + t;
+                *reinterpret_cast<float2*>(a.part_ml + prow * 2) = float2{m_run, l_run};
             }
-        if (a.n_splits > 1 && valid && hi == 0) {
-            const size_t prow = ((size_t)sp * a.H + qh) * m.T + t;
-            *reinterpret_cast<float2*>(a.part_ml + prow * 2) = float2{m_run, l_run};
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     wg_barrier();
+    dbg_stamp(a, 7);
     // ---- every wave stores whole 2D-byte rows (16 bytes per lane): the store tail is issue bound, so it is spread over all waves
     constexpr int CPR = 2 * D / 16;                    // 16-B chunks per output row
     uint16_t* obase = a.n_splits == 1 ? a.out : a.part_o + (size_t)sp * m.T * a.H * D;
@@ -620,7 +688,7 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
         const int row = idx / CPR, c = idx % CPR;
         int hg2, t2;
         split_row(row0 + row, hg2, t2);
-        const u32x4 v = *reinterpret_cast<const u32x4*>(stg_base + (size_t)(row >> 5) * STG_STRIDE + (row & 31) * RS + c * 16);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(stg_base + (size_t)(row >> 5) * stg_stride + (row & 31) * RS + c * 16);
         *reinterpret_cast<u32x4*>(obase + (size_t)t2 * ostride + (size_t)(kvh * n_rep + hg2) * D + c * 8) = v;
     }
     dbg_stamp(a, 5);

@@ -170,7 +170,7 @@ def test_reference_default_configuration_w60_n8_g60():
 
 def test_graph_recapture_when_the_cache_outgrows_its_split_count():
     """bf16, 2600 new tokens in graph mode: the KV split count of the captured attention follows the cache length
-    (re-capture), the run completes, and its head equals an eager run (identical rounding while the split counts agree)."""
+    (re-capture), the run completes, and its head is the eager run's - or parts from it only at a rounding near-tie."""
     from lookaheaddecoding_amd.decoding import LookaheadDecoder
     cfg, w, eng = make_engine("tiny-d128", torch.bfloat16, 2, 0.05, max_seq=4096)
     prompt = [1, 5, 9, 17, 33, 5, 9, 17, 44, 5, 9]
@@ -182,7 +182,13 @@ def test_graph_recapture_when_the_cache_outgrows_its_split_count():
     assert out.generated == 2600 and all(0 <= t < cfg["vocab"] for t in out.tokens)
     assert len(captures) >= 2 and captures[-1] > 1024, captures
     eager = LookaheadDecoder(eng, 7, 4, 7).greedy(prompt, len(prompt) + 300, rng=random.Random(5))
-    assert eager.tokens == out.tokens[:len(eager.tokens)]
+    # Same kernels, same split COUNT - but the graph step pads its candidate slots, so the key count P + T and with it the boundaries of
+    # the contiguous KV splits can differ from the eager step's by one tile: 16-bit partials then round differently, and the two greedy
+    # streams may part at a near-tie.  Where they do, both must still be greedy streams of the model (fp32 oracle margin).
+    head = out.tokens[:len(eager.tokens)]
+    if eager.tokens != head:
+        assert _oracle_margin_check(cfg, w, torch.bfloat16, eager.tokens, len(prompt), tol=0.06)
+        assert _oracle_margin_check(cfg, w, torch.bfloat16, head, len(prompt), tol=0.06)
 
 
 def test_sampling_fp32_identical_tokens_vs_reference():
