@@ -520,7 +520,7 @@ def worker(args):
         us_iso, how = us, "isolated (no in-step measurement in this mode)"
         if graph_delta is not None and graph_delta["us"] > 0:
             us, how = graph_delta["us"], "hipGraph step time with / without the attention launches"
-        elif in_situ is not None and in_situ["T"] == T_k and in_situ["gpu_bound"]:
+        elif in_situ is not None and abs(in_situ["T"] - T_k) <= gs and in_situ["gpu_bound"]:      # within one stray candidate of the steady shape
             us, ns, how = in_situ["us"], in_situ["n_splits"], "hipEvents inside real decode steps, minus what an empty event bracket reads"
         alg = attn_algorithmic_bytes(cfg, T_k, P_end)
         flops = attn_useful_flops(cfg, T_k, P_end, W, N, g_mid) if not use_lp else 4 * cfg["head_dim"] * cfg["heads"] * T_k * P_end
