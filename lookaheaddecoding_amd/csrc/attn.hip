@@ -350,26 +350,42 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
     // ---- LDS-DMA (no VGPR staging): the split's first NSTG stages are requested before the row bookkeeping; a tile that lies
     // beyond the split is a harmless read inside the cache allocation (an L2 hit of the split's first tile) and is never computed on
     const int last_tile = a.S_max / KT - 1;
+    // per-lane byte offsets of this wave's pieces inside a K tile / a V^T tile, resolved ONCE: a piece of a tile is then (wave-uniform tile
+    // base) + (32-bit lane offset) - one scalar add per piece instead of a 64-bit multiply-add per lane.  (The prologue's 16 pieces per wave
+    // took 4 k cycles to issue; every cycle of it delays the moment the split's stream is fully requested.)
+    uint32_t k_off[KPW], v_off[VPW];
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+        const int piece = wave * KPW + i;
+        const int row = piece * (64 / K_CPR) + lane / K_CPR;
+        const int c = (lane % K_CPR) ^ swz16<2 * D>(row);
+        k_off[i] = (uint32_t)(row * D + c * 8) * 2u;
+    }
+#pragma unroll
+    for (int i = 0; i < VPW; ++i) {
+        const int piece = wave * VPW + i;
+        const int row = piece * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ swz16<2 * KT>(row);
+        v_off[i] = ((uint32_t)row * (uint32_t)a.S_max + (uint32_t)(c * 8)) * 2u;
+    }
+    const unsigned char* kbytes = reinterpret_cast<const unsigned char*>(kbase);
+    const unsigned char* vbytes = reinterpret_cast<const unsigned char*>(vbase);
     auto issue_tiles = [&](int stage, int ts, int tile) {
         const int k0 = min(tile, last_tile) * KT;
         unsigned char* ks = smem + stage * STAGE_BYTES + ts * TILE_BYTES;
         unsigned char* vs = ks + K_BYTES;
+        const unsigned char* kt = kbytes + (size_t)k0 * D * 2;          // wave uniform
+        const unsigned char* vt = vbytes + (size_t)k0 * 2;
 #pragma unroll
         for (int i = 0; i < KPW; ++i) {
             const int piece = wave * KPW + i;
-            const int row = piece * (64 / K_CPR) + lane / K_CPR;
-            const int c = (lane % K_CPR) ^ swz16<2 * D>(row);
-            const uint16_t* src = kbase + (size_t)(k0 + row) * D + c * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kt + k_off[i]),
                                              (__attribute__((address_space(3))) void*)(ks + piece * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < VPW; ++i) {
             const int piece = wave * VPW + i;
-            const int row = piece * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ swz16<2 * KT>(row);
-            const uint16_t* src = vbase + (size_t)row * a.S_max + k0 + c * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vt + v_off[i]),
                                              (__attribute__((address_space(3))) void*)(vs + piece * 1024), 16, 0, 0);
         }
     };
