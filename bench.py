@@ -473,9 +473,7 @@ def worker(args):
 
     def hot_regime():
         Cy = 256
-        for lw in eng.layers:
-            lw["wo"].zero_()
-            lw["wd"].zero_()
+        eng.zero_projections(("wo", "wd"))
         head = eng.embed.clone()
         head[:Cy] = eng.embed[(torch.arange(Cy, device=dev) - 1) % Cy]
         eng.lm_head = head
@@ -556,7 +554,10 @@ def worker(args):
                                    f"W={W} N={N} G={G}, cold regime (untied random weights)", "name": args.config,
                        "parallelism": f"lp{world}" if use_lp else "single", "collective_ranks": collective_ranks, "collective": collective_kind,
                        "tokens_per_step_T": round(avg_T, 1), "kv_len_end": P_end,
-                       "hipgraph": bool(dec.use_graph), **({"shared_gpu": True, "backend": backend} if share_gpu else {})},
+                       "hipgraph": bool(dec.use_graph),
+                       "weight_layout": (f"decode GEMMs stream a K-tile-major copy of the projection weights (+{eng.ktile_bytes / 1e9:.1f} GB of HBM); "
+                                         "prefill uses the row-major ones" if eng.ktile else "row-major (the K-tile-major copy does not fit or is disabled)"),
+                       **({"shared_gpu": True, "backend": backend} if share_gpu else {})},
             "step_compression": round(S, 3), "steps_per_s": round(args.steps / elapsed, 2), "spread": spread,
             "prefill": {"tokens": args.prompt_len + W + N - 3, "ms": round(prefill_s * 1e3, 2), "tokens_per_s": round((args.prompt_len + W + N - 3) / prefill_s, 1),
                         "how": f"prompt + first window level as causal chunks of <= {args.chunk} rows through the same attention / GEMM kernels, lm_head on the "

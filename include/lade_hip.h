@@ -41,7 +41,7 @@
  *   lade_rmsnorm / lade_add_rmsnorm / lade_silu_mul / lade_gather_rows   LlamaRMSNorm (+ residual add), SwiGLU,
  *                            embedding / logits-row gather around the GEMMs
  *                            lade/models/modeling_llama.py:222-227, :360-380, :1164 ("next" row)
- *   lade_gemm_skinny / lade_splitk_reduce   the nn.Linear projections of the step at M = T <= 128 rows
+ *   lade_gemm_skinny / lade_gemm_skinny_kt / lade_weight_to_ktile / lade_splitk_reduce   the nn.Linear projections of the step at M = T <= 128 rows
  *                            lade/models/modeling_llama.py:360-380 (MLP), :492-494, :558 (q/k/v/o)
  *   lade_rope_kv_append_parts / lade_add_rmsnorm_parts / lade_silu_mul_parts   the same glue ops taking that
  *                            GEMM's fp32 split-K partials as input (the reduction is fused into the consumer)
@@ -323,6 +323,15 @@ int lade_gather_rows(const void* src, const int32_t* idx, void* dst, int32_t row
 int lade_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, float* Cpart,
                      int32_t M, int32_t N, int32_t K, int32_t n_split, int32_t bn, int32_t mb, int32_t mt, int32_t nt,
                      int32_t epilogue, int32_t dtype, void* stream);
+/* The same GEMM on a weight stored K-TILE-MAJOR: Wkt[K/64][N][64], i.e. Wkt[kt][n][j] = W[n][64 kt + j] - the 128-byte segments of all N
+ * rows of one 64-deep K tile are contiguous.  Row-major nn.Linear weights (lade/models/modeling_llama.py:360-380, 492-494, 558) make a
+ * work-group's K tile BN separate 128-byte reads K elements apart; K-tile-major makes it ONE contiguous BN x 128 bytes, and the
+ * work-groups of a split sweep memory linearly as they walk along K.  Same arithmetic in the same order: results are bit-identical to
+ * lade_gemm_skinny.  lade_weight_to_ktile builds the copy once at load time (out of place; K % 64 == 0). */
+int lade_gemm_skinny_kt(const void* A, int64_t lda, const void* Wkt, void* C, int64_t ldc, float* Cpart,
+                        int32_t M, int32_t N, int32_t K, int32_t n_split, int32_t bn, int32_t mb, int32_t mt, int32_t nt,
+                        int32_t epilogue, int32_t dtype, void* stream);
+int lade_weight_to_ktile(const void* W, int64_t ldw, void* Wkt, int32_t N, int32_t K, int32_t dtype, void* stream);
 /* consumers that take a GEMM output as n_parts fp32 split-K partials [n_parts][rows][width] (part_stride elements
  * apart), sum them in split order and round once to the model dtype - so the split-K GEMM needs no reduce pass */
 int lade_add_rmsnorm_parts(void* x, const float* parts, int32_t n_parts, int64_t part_stride, const void* weight, void* y,

@@ -32,6 +32,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, u
     *reinterpret_cast<u32x2*>(C + (size_t)m * ldc + i) = w;
 }
 
+// output chunk c (16 bytes) of the K-tile-major weight: c = (kt * N + n) * 8 + j  <-  W[n][64 kt + 8 j ..]
+__global__ __launch_bounds__(256) void weight_to_ktile_kernel(const uint16_t* W, int64_t ldw, uint16_t* Wkt, int N, int K) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= (int64_t)N * (K / 8)) return;
+    const int j = (int)(c & 7);
+    const int64_t row = c >> 3;                     // kt * N + n
+    const int kt = (int)(row / N), n = (int)(row - (int64_t)kt * N);
+    *reinterpret_cast<u32x4*>(Wkt + c * 8) = *reinterpret_cast<const u32x4*>(W + (size_t)n * ldw + (size_t)kt * G_BK + j * 8);
+}
+
 }  // namespace lade
 
 using namespace lade;
@@ -39,9 +49,9 @@ using namespace lade;
 // bn: weight rows per work-group (32..256); mb: 32-row activation blocks per work-group (1..4; 0 = by M); mt: m-blocks per
 // wave (1 | 2 | 3 | 4, divides mb; 0 = 1); nt: 32-row weight tiles per wave (1..4; 0 = spread the tiles over as many n-groups
 // as there are waves).  The waves form an (mb/mt) x (bn/32/nt) grid.  Only the shapes in the table of gemm_kernel.hpp are built.
-extern "C" int lade_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, float* Cpart,
-                                int32_t M, int32_t N, int32_t K, int32_t n_split, int32_t bn, int32_t mb, int32_t mt, int32_t nt,
-                                int32_t epilogue, int32_t dtype, void* stream) {
+static int gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, bool ktile, void* C, int64_t ldc, float* Cpart,
+                       int32_t M, int32_t N, int32_t K, int32_t n_split, int32_t bn, int32_t mb, int32_t mt, int32_t nt,
+                       int32_t epilogue, int32_t dtype, void* stream) {
     LADE_REQUIRE(epilogue == 0 || (epilogue == 1 && n_split == 1 && N % 32 == 0 && C != nullptr), LADE_E_ARG,
                  "lade_gemm_skinny: epilogue=%d needs n_split == 1, N %% 32 == 0 and an output matrix", epilogue);
     LADE_REQUIRE(A && W && M > 0 && N > 0 && K > 0 && n_split >= 1, LADE_E_ARG, "lade_gemm_skinny: M=%d N=%d K=%d split=%d", M, N, K, n_split);
@@ -66,12 +76,39 @@ extern "C" int lade_gemm_skinny(const void* A, int64_t lda, const void* W, int64
     GemmK g;
     g.A = (const uint16_t*)A; g.W = (const uint16_t*)W; g.C = (uint16_t*)C; g.Cpart = Cpart;
     g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.n_split = n_split;
+    g.w_ts = ktile ? (int64_t)N * G_BK : 0;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("LADE_GEMM_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
     g.epi = epilogue;
     hipStream_t st = (hipStream_t)stream;
     const int rc = dtype == LADE_BF16 ? gemm_dispatch_bf16(g, st, mw, mt, ng, nt) : gemm_dispatch_f16(g, st, mw, mt, ng, nt);
     if (rc >= 0) return rc;
     LADE_REQUIRE(false, LADE_E_ARG, "lade_gemm_skinny: no kernel for mb=%d mt=%d bn=%d nt=%d (wave grid %d x %d)", mb, mt, bn, nt, mw, ng);
+}
+
+extern "C" int lade_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, float* Cpart,
+                                int32_t M, int32_t N, int32_t K, int32_t n_split, int32_t bn, int32_t mb, int32_t mt, int32_t nt,
+                                int32_t epilogue, int32_t dtype, void* stream) {
+    return gemm_skinny(A, lda, W, ldw, false, C, ldc, Cpart, M, N, K, n_split, bn, mb, mt, nt, epilogue, dtype, stream);
+}
+
+// The same GEMM on a weight stored K-tile-major: Wkt[K/64][N][64] (lade_weight_to_ktile).  Same arithmetic in the same order, so the
+// results are bit-identical to lade_gemm_skinny on the row-major weight; only the addresses the weight DMA reads differ.
+extern "C" int lade_gemm_skinny_kt(const void* A, int64_t lda, const void* Wkt, void* C, int64_t ldc, float* Cpart,
+                                   int32_t M, int32_t N, int32_t K, int32_t n_split, int32_t bn, int32_t mb, int32_t mt, int32_t nt,
+                                   int32_t epilogue, int32_t dtype, void* stream) {
+    return gemm_skinny(A, lda, Wkt, 8, true, C, ldc, Cpart, M, N, K, n_split, bn, mb, mt, nt, epilogue, dtype, stream);
+}
+
+// Wkt[kt][n][0..63] = W[n][64 kt .. 64 kt + 63]: one 16-byte chunk per thread, a wave writes 1 KiB contiguous
+extern "C" int lade_weight_to_ktile(const void* W, int64_t ldw, void* Wkt, int32_t N, int32_t K, int32_t dtype, void* stream) {
+    LADE_REQUIRE(W && Wkt && W != Wkt && N > 0 && K > 0 && K % G_BK == 0 && ldw >= K && ldw % 8 == 0, LADE_E_ARG,
+                 "lade_weight_to_ktile: N=%d K=%d ldw=%lld (K must be a multiple of %d, out of place)", N, K, (long long)ldw, G_BK);
+    LADE_REQUIRE(dtype == LADE_BF16 || dtype == LADE_F16, LADE_E_DTYPE, "lade_weight_to_ktile: dtype=%d", dtype);
+    const int64_t chunks = (int64_t)N * (K / 8);
+    LADE_REQUIRE(chunks / 256 + 1 < (int64_t)1 << 31, LADE_E_LIMIT, "lade_weight_to_ktile: N=%d K=%d too large", N, K);
+    hipLaunchKernelGGL(weight_to_ktile_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)W, ldw, (uint16_t*)Wkt, N, K);
+    return check_launch("lade_weight_to_ktile");
 }
 
 extern "C" int lade_splitk_reduce(const float* part, void* C, int64_t ldc, int32_t M, int32_t N, int32_t n_split, int32_t dtype, void* stream) {

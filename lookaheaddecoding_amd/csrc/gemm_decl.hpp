@@ -11,10 +11,11 @@ constexpr int G_BK = 64;          // K depth of one LDS tile (128-byte rows)
 
 struct GemmK {
     const uint16_t* A;     // [M][lda]
-    const uint16_t* W;     // [N][ldw]
+    const uint16_t* W;     // [N][ldw], or [K/64][N][64] (w_ts != 0)
     uint16_t* C;           // [M][ldc] model dtype (n_split == 1)
     float* Cpart;          // [n_split][M][N] fp32 (n_split > 1)
     int64_t lda, ldw, ldc;
+    int64_t w_ts;          // 0: W is row-major [N][ldw];  64 N: W is K-tile-major [K/64][N][64] (elements between the K tiles of a row)
     int M, N, K, n_split;
     int dbg;               // ablation switches for tools/gemm_ablate.py (LADE_GEMM_DBG): 1 = no output stores, 4 = no LDS reads / MFMA
     int epi;               // n_split == 1 only: 0 = C = A.W^T;  1 = SwiGLU over interleaved gate / up rows, C is [M][N/2]

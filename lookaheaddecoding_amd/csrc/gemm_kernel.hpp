@@ -89,6 +89,10 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
     // inside a stage.  Inside the K loop a piece then costs one 64-bit add, the M0 write
     // and the global_load_lds.  (Left inside the loop, the address arithmetic - two clamps, a 64-bit multiply, and the kernel
     // arguments re-read through the scalar cache after every asm barrier - cost a wave ~120 ns per piece: more than the transfer.)
+    // weight addressing: row-major W[N][ldw] (a K tile of a row = 128 bytes, rows ldw apart) or K-tile-major Wkt[K/64][N][64] (g.w_ts =
+    // 64 N: the 128-byte segments of ALL rows of one K tile are contiguous, so a 1-KiB DMA piece is one contiguous KiB, a work-group's
+    // tile one contiguous BN x 128 bytes, and the work-groups of a split sweep memory linearly as they walk along K)
+    const int64_t w_rs = g.w_ts ? G_BK : g.ldw, w_ts = g.w_ts ? g.w_ts : G_BK;
     const bool moves = wave * PIECES < TOTAL_PIECES;     // a wave moves PIECES pieces or none (vmcnt is per wave: nothing requested, nothing to wait for)
     const uint16_t* p_src[PIECES];
     int p_dst[PIECES];
@@ -101,7 +105,8 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
         const int p = isw ? piece : piece - W_PIECES;
         const int row = p * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
-        p_src[i] = (isw ? g.W + (size_t)min(n0 + row, g.N - 1) * g.ldw : g.A + (size_t)min(m0 + row, g.M - 1) * g.lda) + (size_t)t0 * G_BK + c * 8;
+        p_src[i] = (isw ? g.W + (size_t)min(n0 + row, g.N - 1) * w_rs + (size_t)t0 * w_ts
+                        : g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + (size_t)t0 * G_BK) + c * 8;
         p_dst[i] = (isw ? 0 : W_BYTES) + p * 1024;
         p_w[i] = isw;
     }
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
         unsigned char* sbase = smem + stage * STAGE;
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
-            const uint16_t* src = p_src[i] + j * G_BK;
+            const uint16_t* src = p_src[i] + (int64_t)j * (p_w[i] ? w_ts : (int64_t)G_BK);
             unsigned char* dst = sbase + p_dst[i];
             // the weight stream is non-temporal (aux = 2): every weight byte is read by exactly one work-group, once per step, so
             // keeping it in L2 / the Infinity Cache only evicts what is re-read (activation tiles, partials).  Measured on the four

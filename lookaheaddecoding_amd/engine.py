@@ -13,10 +13,11 @@ mask, a torch.cat of the whole KV cache per layer and lm_head over all T rows.  
 
 with a preallocated KV cache ([L][2][Hkv*S_max*d]; keys row-major, values transposed) sized for
 the 288 GB of HBM.  The projections of steps of <= 256 rows run on the hand-written weight-streaming
-split-K GEMM (`lade_gemm_skinny`; its fp32 partials are summed by the consumer kernels, the gate/up
+split-K GEMM (`lade_gemm_skinny_kt` on a K-tile-major copy of the weights where it fits the HBM, else
+`lade_gemm_skinny` on the row-major ones; its fp32 partials are summed by the consumer kernels, the gate/up
 GEMM carries SwiGLU in its epilogue) wherever the per-shape autotune finds it faster than the
 library GEMM (hipBLASLt through torch.matmul); wider steps (prefill chunks), fp32 and the lm_head use
-the library.  No CPU fallback: construction fails without the HIP extension or without a GPU.
+the library on the row-major weights.  No CPU fallback: construction fails without the HIP extension or without a GPU.
 """
 from __future__ import annotations
 
@@ -131,14 +132,16 @@ class StepEngine:
                 wo=W(p + "wo").contiguous(),
                 wgu=self._fuse_gate_up(W(p + "wg"), W(p + "wu")),
                 wd=W(p + "wd").contiguous()))
+        # hand-written weight-streaming GEMM (split-K partials consumed by the fused glue kernels) for steps of
+        # <= 256 tokens; every (N, K, row class) is timed against the library GEMM once and the faster one is kept
+        self.custom_gemm = dt != torch.float32 and os.environ.get("LADE_GEMM", "1") != "0" and self.d % 16 == 0 and self.hidden % 64 == 0 and self.inter % 64 == 0
+        self.ktile, self.ktile_bytes = False, 0
+        self._build_ktile_copies()
         self._alloc_cache(self.S_max)
         self.attn_events = None             # set to a list to collect (start, end, T, n_splits) hipEvent pairs per layer
         self.attn_events_empty = None       # ... and back-to-back event pairs (what an empty bracket reads)
         self.skip_attn = False              # bench.py only: leave the attention launches out (step-time difference = their cost)
         self.max_splits = 32
-        # hand-written weight-streaming GEMM (split-K partials consumed by the fused glue kernels) for steps of
-        # <= 128 tokens; every (N, K, row class) is timed against the library GEMM once and the faster one is kept
-        self.custom_gemm = dt != torch.float32 and os.environ.get("LADE_GEMM", "1") != "0" and self.d % 16 == 0 and self.hidden % 64 == 0 and self.inter % 64 == 0
         self.gemm_cfg = {}
         self._alloc_workspaces(max_T)
         try:
@@ -152,6 +155,43 @@ class StepEngine:
         Shapes whose intermediate size is not a multiple of 16 keep the plain [gate | up] concatenation (layout 0)."""
         self.gu_layout = 1 if wg.shape[0] % 16 == 0 else 0
         return ops.interleave_gate_up(wg, wu) if self.gu_layout else torch.cat([wg, wu], dim=0).contiguous()
+
+    # ---- weight layout of the decode GEMMs ----------------------------------------------------------------
+    KTILE_RESERVE = 24 << 30             # HBM left free for the KV cache, workspaces and the library's own buffers when the copies are made
+
+    def _build_ktile_copies(self) -> None:
+        """A second, K-TILE-MAJOR copy ([K/64][N][64], `lade_weight_to_ktile`) of every projection weight for the skinny GEMM: the 128-byte
+        segments of all rows of one K tile are contiguous, so a work-group's tile is one contiguous read and the work-groups of a split
+        sweep memory linearly (7B projections at 60 rows: 88.8 -> 79.2 us per layer, bit-identical results).  The row-major
+        weights stay for the library GEMM (prefill chunks, steps wider than 256 rows).  This spends HBM to buy bandwidth - 13 GB more at
+        7B, 26 GB at 13B of the 288 GB - and is skipped when the copies would not fit (Llama-2-70B in bf16 keeps the row-major path).
+        LADE_W_KTILE=0 / 1 overrides the decision."""
+        want = os.environ.get("LADE_W_KTILE", "auto")
+        if not self.custom_gemm or want == "0":
+            return
+        extra = sum(lw[n].numel() * lw[n].element_size() for lw in self.layers for n in self.GEMM_NAMES)
+        if want != "1":
+            free, _total = torch.cuda.mem_get_info(self.device)
+            if free < extra + self.KTILE_RESERVE:
+                return
+        with torch.cuda.device(self.device):            # the C ABI launches on the current device's current stream
+            for lw in self.layers:
+                for n in self.GEMM_NAMES:
+                    lw[n + "_kt"] = ops.to_ktile(lw[n])
+        self.ktile = True
+        self.ktile_bytes = extra
+
+    def zero_projections(self, names: Sequence[str]) -> None:
+        """bench / tests (successor-map models): zero the named projections of every layer in every layout the engine holds"""
+        for lw in self.layers:
+            for n in names:
+                lw[n].zero_()
+                if n + "_kt" in lw:
+                    lw[n + "_kt"].zero_()
+
+    def _w(self, lw: dict, name: str) -> torch.Tensor:
+        """the weight the skinny GEMM streams: the K-tile-major copy when the engine holds one"""
+        return lw[name + "_kt"] if self.ktile else lw[name]
 
     def _alloc_cache(self, S_max: int, keep_rows: int = 0) -> None:
         """KV cache [L][2][Hkv*S_max*d] (K: [Hkv][S_max][d], V: [Hkv][d][S_max]), zero-initialised; RoPE tables for it.
@@ -237,12 +277,13 @@ class StepEngine:
             return self.gemm_cfg[key]
         ws = [lw[name] for lw in self.layers]
         N, K = ws[0].shape
+        ws = (ws, [self._w(lw, name) for lw in self.layers])       # (row-major: library GEMM, what the skinny GEMM streams)
         # one decision per (shape, row class, dtype) and process: engines of the same model (lookahead-parallel ranks run as
         # threads, a decoder rebuilt on the same weights) must pick the same kernel, or their 16-bit results round differently
         # (the gate/up decision differs from a plain projection of the same shape - SwiGLU tail cost, fused-epilogue variant - and
         # timings taken on one GPU model do not transfer to another)
         gkey = (int(N), int(K), mclass, str(self.dtype), name == "wgu", self.gu_layout if name == "wgu" else 0,
-                torch.cuda.get_device_name(self.device), self.n_cu)
+                torch.cuda.get_device_name(self.device), self.n_cu, self.ktile)
         with _TUNE_LOCK:
             if gkey in _TUNE_CACHE:
                 self.gemm_cfg[key] = _TUNE_CACHE[gkey]
@@ -253,6 +294,7 @@ class StepEngine:
         return best
 
     def _tune_timed(self, name: str, mclass: int, ws, N: int, K: int):
+        ws_lib, ws = ws
         a = torch.randn({32: 30, 64: 60, 96: 92, 128: 128, 192: 180, 256: 240}[mclass], K, device=self.device).to(self.dtype)
         out = torch.empty(a.shape[0], N, dtype=self.dtype, device=self.device)
         cands = []
@@ -297,7 +339,7 @@ class StepEngine:
         tail = (lambda out_bytes: 0.0025 + out_bytes / 4e9) if name == "wgu" else (lambda out_bytes: 0.0)
         if name == "wgu" and os.environ.get("LADE_GU_TAIL_FIXED"):          # experiment: the flat 6 us estimate
             tail = lambda out_bytes: 0.006
-        t_lib = time_it(lambda i: torch.matmul(a, ws[i % len(ws)].t(), out=out)) + 0.003 + tail(Mrows * N * 2)      # + the consumer's extra read
+        t_lib = time_it(lambda i: torch.matmul(a, ws_lib[i % len(ws_lib)].t(), out=out)) + 0.003 + tail(Mrows * N * 2)      # + the consumer's extra read
         timed = []                        # (ms incl. the consumer tail, (mb, bn, S, mt, nt))
         for (mb, bn, S, mt, nt) in cands:
             t = time_it(lambda i: ops.gemm_parts(a, ws[i % len(ws)], self.ws_part, S, bn, mb, mt, nt)) + tail(S * Mrows * N * 4)
@@ -321,7 +363,7 @@ class StepEngine:
         if timed and min(timed)[0] < t_lib:
             t_best, best = min(timed)
         if os.environ.get("LADE_TUNE_VERBOSE"):          # tools/gemm_tune_probe.py: what the tuner saw
-            mbytes = N * K * ws[0].element_size() / 1e6
+            mbytes = N * K * ws_lib[0].element_size() / 1e6
             top = " ".join(f"{c}:{t * 1e3:.1f}" for t, c in sorted(timed)[:6])
             print(f"[tune] {name}:{mclass} rows={Mrows} N={N} K={K} lib {t_lib * 1e3:.1f} us | best {best} {t_best * 1e3:.1f} us "
                   f"({mbytes / (t_best * 1e3):.2f} TB/s) | {top}", file=sys.stderr, flush=True)
@@ -373,7 +415,7 @@ class StepEngine:
             else:
                 ops.add_rmsnorm(x, r, lw["ln1"], self.eps, out=h)
             if cfg_qkv:
-                ops.gemm_parts(h, lw["wqkv"], part, cfg_qkv[2], cfg_qkv[1], cfg_qkv[0], cfg_qkv[3], cfg_qkv[4])
+                ops.gemm_parts(h, self._w(lw, "wqkv"), part, cfg_qkv[2], cfg_qkv[1], cfg_qkv[0], cfg_qkv[3], cfg_qkv[4])
                 qb = self.ws_q[:T]
                 ops.rope_kv_append_parts(part, cfg_qkv[2], qb, pos, self.cos, self.sin, self.k_cache(li), self.vt_cache(li), T, P, H=H, Hkv=Hkv, d=d, dyn_P=dyn_P)
                 q_in = qb
@@ -398,21 +440,21 @@ class StepEngine:
                 e1.record()
                 ev.append((e0, e1, mask.T, n_splits))
             if cfg_o:
-                ops.gemm_parts(o, lw["wo"], part, cfg_o[2], cfg_o[1], cfg_o[0], cfg_o[3], cfg_o[4])
+                ops.gemm_parts(o, self._w(lw, "wo"), part, cfg_o[2], cfg_o[1], cfg_o[0], cfg_o[3], cfg_o[4])
                 ops.add_rmsnorm_parts(x, part, cfg_o[2], lw["ln2"], self.eps, out=h)      # x += attn; h = norm(x)
             else:
                 torch.matmul(o, lw["wo"].t(), out=r)
                 ops.add_rmsnorm(x, r, lw["ln2"], self.eps, out=h)
             if cfg_gu and cfg_gu[2] == 1:                 # gate/up GEMM + SwiGLU in one launch
-                ops.gemm_swiglu(h, lw["wgu"], a, cfg_gu[1], cfg_gu[0], cfg_gu[3], cfg_gu[4])
+                ops.gemm_swiglu(h, self._w(lw, "wgu"), a, cfg_gu[1], cfg_gu[0], cfg_gu[3], cfg_gu[4])
             elif cfg_gu:
-                ops.gemm_parts(h, lw["wgu"], part, cfg_gu[2], cfg_gu[1], cfg_gu[0], cfg_gu[3], cfg_gu[4])
+                ops.gemm_parts(h, self._w(lw, "wgu"), part, cfg_gu[2], cfg_gu[1], cfg_gu[0], cfg_gu[3], cfg_gu[4])
                 ops.silu_mul_parts(part, cfg_gu[2], T, self.inter, out=a, layout=self.gu_layout)
             else:
                 torch.matmul(h, lw["wgu"].t(), out=gu)
                 ops.silu_mul(gu, out=a, layout=self.gu_layout)
             if cfg_d:
-                ops.gemm_parts(a, lw["wd"], part, cfg_d[2], cfg_d[1], cfg_d[0], cfg_d[3], cfg_d[4])
+                ops.gemm_parts(a, self._w(lw, "wd"), part, cfg_d[2], cfg_d[1], cfg_d[0], cfg_d[3], cfg_d[4])
                 r_parts = cfg_d[2]
             else:
                 torch.matmul(a, lw["wd"].t(), out=r)

@@ -157,9 +157,7 @@ def test_fullsize_shapes_end_to_end_on_a_successor_model(shape, layers, W, N, G)
     eng = StepEngine(cfg, w, dtype=torch.bfloat16, device="cuda", max_seq=1024, max_T=512)
     del w
     C = 256
-    for lw in eng.layers:
-        lw["wo"].zero_()
-        lw["wd"].zero_()
+    eng.zero_projections(("wo", "wd"))
     head = eng.embed.clone()
     head[:C] = eng.embed[(torch.arange(C, device="cuda") - 1) % C]
     eng.lm_head = head

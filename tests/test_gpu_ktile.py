@@ -1,0 +1,131 @@
+"""K-tile-major weights for the decode GEMMs (`lade_weight_to_ktile`, `lade_gemm_skinny_kt`, the engine's second weight copy).
+
+The layout changes only the addresses the weight DMA reads: the arithmetic and its order are those of `lade_gemm_skinny`, so every
+comparison here is BIT-EXACT against the row-major path, which the other GPU tests compare with torch / the fp32 oracle.
+Reference: the nn.Linear projections of the step, lade/models/modeling_llama.py:360-380, 492-494, 558."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from lookaheaddecoding_amd.weights import make_config, random_weights_numpy
+
+
+def test_weight_to_ktile_is_the_permutation_and_refuses_bad_shapes():
+    from lookaheaddecoding_amd import cabi, ops
+    torch.manual_seed(0)
+    for dtype in (torch.bfloat16, torch.float16):
+        for (N, K) in ((160, 320), (8, 64), (1000, 192), (4096, 11008)):
+            w = torch.randn(N, K, device="cuda").to(dtype)
+            assert torch.equal(ops.to_ktile(w), w.view(N, K // 64, 64).permute(1, 0, 2).contiguous()), (N, K, dtype)
+        w = torch.randn(96, 256, device="cuda").to(dtype)[:, :192]                  # a row stride larger than K
+        assert torch.equal(ops.to_ktile(w), w.reshape(96, 3, 64).permute(1, 0, 2).contiguous())
+    w = torch.randn(32, 96, device="cuda").bfloat16()
+    out = torch.empty(2, 32, 64, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(cabi.LadeHipError):                                          # K % 64 != 0
+        cabi.call("lade_weight_to_ktile", cabi.ptr(w), 96, cabi.ptr(out), 32, 96, cabi.dtype_code(w))
+    w = torch.randn(32, 128, device="cuda").bfloat16()
+    with pytest.raises(cabi.LadeHipError):                                          # in place
+        cabi.call("lade_weight_to_ktile", cabi.ptr(w), 128, cabi.ptr(w), 32, 128, cabi.dtype_code(w))
+    with pytest.raises(cabi.LadeHipError):                                          # fp32 has no skinny GEMM
+        cabi.call("lade_weight_to_ktile", cabi.ptr(w), 128, cabi.ptr(out), 32, 128, 2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_on_ktile_weights_is_bit_identical_to_row_major(dtype):
+    """every row class (32 ... 256 rows), split-K partials and the direct output, weight rows that do not fill the last work-group
+    (the clamped tail), one K tile per split, 7B-sized strides"""
+    from lookaheaddecoding_amd import ops
+    torch.manual_seed(1)
+    cases = [  # M, N, K, (bn, mb, mt, nt), splits
+        (30, 1000, 512, (128, 1, 1, 0), (1, 2, 4)),
+        (60, 4096, 4096, (128, 2, 2, 0), (1, 8)),
+        (60, 1000, 1024, (96, 2, 1, 1), (1, 2)),
+        (92, 264, 256, (64, 3, 1, 0), (1, 2, 4)),
+        (128, 776, 512, (192, 4, 2, 0), (1, 3)),
+        (180, 520, 384, (128, 6, 3, 1), (1, 2)),
+        (240, 1032, 640, (64, 8, 4, 1), (1, 5)),
+        (1, 12288, 4096, (96, 1, 1, 1), (2,)),
+        (7, 64, 64, (64, 1, 1, 0), (1,)),
+    ]
+    for (M, N, K, (bn, mb, mt, nt), splits) in cases:
+        a = torch.randn(M, K, device="cuda").to(dtype)
+        w = (torch.randn(N, K, device="cuda") * 0.05).to(dtype)
+        wk = ops.to_ktile(w)
+        for S in splits:
+            if S > 1:
+                p0 = torch.full((S * M * N,), float("nan"), dtype=torch.float32, device="cuda")
+                p1 = torch.full((S * M * N,), float("nan"), dtype=torch.float32, device="cuda")
+                ops.gemm_parts(a, w, p0, S, bn, mb, mt, nt)
+                ops.gemm_parts(a, wk, p1, S, bn, mb, mt, nt)
+                assert torch.isfinite(p0).all() and torch.equal(p0, p1), (M, N, K, S)
+            o0 = ops.gemm_skinny(a, w, n_split=S, bn=bn, mb=mb, mt=mt, nt=nt)
+            o1 = ops.gemm_skinny(a, wk, n_split=S, bn=bn, mb=mb, mt=mt, nt=nt)
+            assert torch.equal(o0, o1), (M, N, K, S)
+            ref = a.float() @ w.float().t()
+            assert torch.allclose(o1.float(), ref, atol=0.02 * K ** 0.5 * 0.05 + 0.02, rtol=2e-2), (M, N, K, S, (o1.float() - ref).abs().max())
+
+
+def test_swiglu_epilogue_on_ktile_weights_is_bit_identical():
+    from lookaheaddecoding_amd import ops
+    torch.manual_seed(2)
+    for (M, inter, K, bn, mt) in ((60, 11008, 4096, 96, 1), (30, 1408, 512, 128, 1), (120, 1792, 1024, 96, 2), (16, 256, 128, 64, 1)):
+        a = torch.randn(M, K, device="cuda").bfloat16()
+        w = ops.interleave_gate_up((torch.randn(inter, K, device="cuda") * 0.05).bfloat16(), (torch.randn(inter, K, device="cuda") * 0.05).bfloat16())
+        mb = 1 if M <= 32 else 2 if M <= 64 else 3 if M <= 96 else 4
+        o0 = torch.full((M, inter), float("nan"), dtype=torch.bfloat16, device="cuda")
+        o1 = torch.full((M, inter), float("nan"), dtype=torch.bfloat16, device="cuda")
+        ops.gemm_swiglu(a, w, o0, bn, mb, mt, 1)
+        ops.gemm_swiglu(a, ops.to_ktile(w), o1, bn, mb, mt, 1)
+        assert torch.isfinite(o0.float()).all() and torch.equal(o0, o1), (M, inter, K)
+
+
+def _engine(monkeypatch, ktile, cfg, w, **kw):
+    from lookaheaddecoding_amd.engine import StepEngine
+    monkeypatch.setenv("LADE_W_KTILE", ktile)
+    return StepEngine(cfg, w, dtype=torch.bfloat16, max_seq=512, max_T=256, **kw)
+
+
+def test_engine_with_and_without_the_ktile_copy_gives_the_same_logits_bit_for_bit(monkeypatch):
+    """two engines on the same weights, one streaming the row-major weights and one the K-tile-major copies, on the SAME GEMM
+    configurations (rank 0's table adopted, as lookahead-parallel ranks do): logits and the appended K/V rows are bit-identical, for a
+    lookahead-shaped step, a one-token step and a 240-row step; zero_projections reaches both layouts"""
+    from lookaheaddecoding_amd import ops
+    cfg = make_config("tiny-d128", max_pos=512)
+    w = {k: torch.as_tensor(v) for k, v in random_weights_numpy(cfg, seed=4, std=0.05).items()}
+    e0 = _engine(monkeypatch, "0", cfg, w)
+    e1 = _engine(monkeypatch, "1", cfg, w)
+    assert not e0.ktile and e1.ktile and all(n + "_kt" in lw for lw in e1.layers for n in e1.GEMM_NAMES)
+    assert not any(k.endswith("_kt") for lw in e0.layers for k in lw)
+    e1.adopt_gemm_cfg(e0.tune_all())
+    g = torch.Generator().manual_seed(5)
+    P = 40
+    prompt = torch.randint(3, cfg["vocab"], (P,), generator=g).tolist()
+    for T in (60, 1, 240):
+        ids = torch.randint(3, cfg["vocab"], (T,), generator=g).to(torch.int32).cuda()
+        pos = (P + torch.arange(T)).to(torch.int32).cuda()
+        sel = torch.arange(T, dtype=torch.int32).cuda()
+        outs = []
+        for e in (e0, e1):
+            e.reset()
+            e.prefill(prompt, rows=[P - 1])
+            lg = e.forward(ids, pos, ops.StepMask(T=T, P=P, is_prefill=True), sel, T)
+            outs.append((lg.clone(), e.k_cache(0)[:, P:P + T].clone(), e.vt_cache(cfg["layers"] - 1)[:, :, P:P + T].clone()))
+        for x, y in zip(*outs):
+            assert torch.isfinite(x.float()).all() and torch.equal(x, y), T
+    e1.zero_projections(("wo", "wd"))
+    assert all(float(lw[n].abs().sum()) == 0.0 for lw in e1.layers for n in ("wo", "wd", "wo_kt", "wd_kt"))
+    assert all(float(lw["wqkv_kt"].abs().sum()) > 0.0 for lw in e1.layers)
+
+
+def test_ktile_copy_is_made_when_it_fits_and_skipped_when_it_does_not(monkeypatch):
+    from lookaheaddecoding_amd.engine import StepEngine
+    cfg = make_config("tiny-d128", max_pos=512)
+    w = {k: torch.as_tensor(v) for k, v in random_weights_numpy(cfg, seed=4, std=0.05).items()}
+    e = _engine(monkeypatch, "auto", cfg, w)
+    assert e.ktile and e.ktile_bytes == sum(lw[n].numel() * 2 for lw in e.layers for n in e.GEMM_NAMES)
+    monkeypatch.setattr(StepEngine, "KTILE_RESERVE", 1 << 50)                      # "the copies do not fit": row-major path, as Llama-2-70B
+    e = _engine(monkeypatch, "auto", cfg, w)
+    assert not e.ktile and e.ktile_bytes == 0
+    e = StepEngine(cfg, w, dtype=torch.float32, max_seq=256, max_T=64)              # fp32 has no skinny GEMM: nothing to copy
+    assert not e.ktile
