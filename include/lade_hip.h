@@ -41,7 +41,7 @@
  *   lade_rmsnorm / lade_add_rmsnorm / lade_silu_mul / lade_gather_rows   LlamaRMSNorm (+ residual add), SwiGLU,
  *                            embedding / logits-row gather around the GEMMs
  *                            lade/models/modeling_llama.py:222-227, :360-380, :1164 ("next" row)
- *   lade_gemm_skinny / lade_gemm_skinny_kt / lade_weight_to_ktile / lade_splitk_reduce   the nn.Linear projections of the step at M = T <= 128 rows
+ *   lade_gemm_skinny / lade_gemm_skinny_kt / lade_weight_to_ktile / lade_weight_from_ktile / lade_splitk_reduce   the nn.Linear projections of the step at M = T <= 128 rows
  *                            lade/models/modeling_llama.py:360-380 (MLP), :492-494, :558 (q/k/v/o)
  *   lade_rope_kv_append_parts / lade_add_rmsnorm_parts / lade_silu_mul_parts   the same glue ops taking that
  *                            GEMM's fp32 split-K partials as input (the reduction is fused into the consumer)
@@ -332,6 +332,9 @@ int lade_gemm_skinny_kt(const void* A, int64_t lda, const void* Wkt, void* C, in
                         int32_t M, int32_t N, int32_t K, int32_t n_split, int32_t bn, int32_t mb, int32_t mt, int32_t nt,
                         int32_t epilogue, int32_t dtype, void* stream);
 int lade_weight_to_ktile(const void* W, int64_t ldw, void* Wkt, int32_t N, int32_t K, int32_t dtype, void* stream);
+/* the inverse, into a caller-provided row-major scratch W[N][ldw]: what a library GEMM needs (prefill chunks wider than 256 rows) when a
+ * model too large to be held twice keeps its projection weights K-tile-major only */
+int lade_weight_from_ktile(const void* Wkt, void* W, int64_t ldw, int32_t N, int32_t K, int32_t dtype, void* stream);
 /* consumers that take a GEMM output as n_parts fp32 split-K partials [n_parts][rows][width] (part_stride elements
  * apart), sum them in split order and round once to the model dtype - so the split-K GEMM needs no reduce pass */
 int lade_add_rmsnorm_parts(void* x, const float* parts, int32_t n_parts, int64_t part_stride, const void* weight, void* y,

@@ -42,6 +42,16 @@ __global__ __launch_bounds__(256) void weight_to_ktile_kernel(const uint16_t* W,
     *reinterpret_cast<u32x4*>(Wkt + c * 8) = *reinterpret_cast<const u32x4*>(W + (size_t)n * ldw + (size_t)kt * G_BK + j * 8);
 }
 
+// the inverse: row-major chunk c = n * (K/8) + kc  <-  Wkt[(kc/8) * N + n][8 (kc % 8) ..]
+__global__ __launch_bounds__(256) void weight_from_ktile_kernel(const uint16_t* Wkt, uint16_t* W, int64_t ldw, int N, int K) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int cpr = K / 8;
+    if (c >= (int64_t)N * cpr) return;
+    const int n = (int)(c / cpr), kc = (int)(c - (int64_t)n * cpr);
+    *reinterpret_cast<u32x4*>(W + (size_t)n * ldw + (size_t)kc * 8) =
+        *reinterpret_cast<const u32x4*>(Wkt + ((size_t)(kc >> 3) * N + n) * G_BK + (kc & 7) * 8);
+}
+
 }  // namespace lade
 
 using namespace lade;
@@ -109,6 +119,19 @@ extern "C" int lade_weight_to_ktile(const void* W, int64_t ldw, void* Wkt, int32
     hipLaunchKernelGGL(weight_to_ktile_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const uint16_t*)W, ldw, (uint16_t*)Wkt, N, K);
     return check_launch("lade_weight_to_ktile");
+}
+
+// W[n][64 kt + j] = Wkt[kt][n][j]: the row-major matrix a library GEMM needs (prefill chunks of a model whose weights are held
+// K-tile-major only), written into a caller-provided scratch
+extern "C" int lade_weight_from_ktile(const void* Wkt, void* W, int64_t ldw, int32_t N, int32_t K, int32_t dtype, void* stream) {
+    LADE_REQUIRE(W && Wkt && W != Wkt && N > 0 && K > 0 && K % G_BK == 0 && ldw >= K && ldw % 8 == 0, LADE_E_ARG,
+                 "lade_weight_from_ktile: N=%d K=%d ldw=%lld (K must be a multiple of %d, out of place)", N, K, (long long)ldw, G_BK);
+    LADE_REQUIRE(dtype == LADE_BF16 || dtype == LADE_F16, LADE_E_DTYPE, "lade_weight_from_ktile: dtype=%d", dtype);
+    const int64_t chunks = (int64_t)N * (K / 8);
+    LADE_REQUIRE(chunks / 256 + 1 < (int64_t)1 << 31, LADE_E_LIMIT, "lade_weight_from_ktile: N=%d K=%d too large", N, K);
+    hipLaunchKernelGGL(weight_from_ktile_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)Wkt, (uint16_t*)W, ldw, N, K);
+    return check_launch("lade_weight_from_ktile");
 }
 
 extern "C" int lade_splitk_reduce(const float* part, void* C, int64_t ldc, int32_t M, int32_t N, int32_t n_split, int32_t dtype, void* stream) {

@@ -16,8 +16,8 @@ the 288 GB of HBM.  The projections of steps of <= 256 rows run on the hand-writ
 split-K GEMM (`lade_gemm_skinny_kt` on a K-tile-major copy of the weights where it fits the HBM, else
 `lade_gemm_skinny` on the row-major ones; its fp32 partials are summed by the consumer kernels, the gate/up
 GEMM carries SwiGLU in its epilogue) wherever the per-shape autotune finds it faster than the
-library GEMM (hipBLASLt through torch.matmul); wider steps (prefill chunks), fp32 and the lm_head use
-the library on the row-major weights.  No CPU fallback: construction fails without the HIP extension or without a GPU.
+library GEMM (hipBLASLt through torch.matmul); the lm_head runs on the same kernel without split-K (rows that are
+read only); wider steps (prefill chunks) and fp32 use the library on the row-major weights.  No CPU fallback: construction fails without the HIP extension or without a GPU.
 """
 from __future__ import annotations
 
@@ -120,7 +120,7 @@ class StepEngine:
         tied = lm is em or (lm.shape == em.shape and lm.dtype == em.dtype and lm.device == em.device and lm.data_ptr() == em.data_ptr())
         self.embed = W("embed").contiguous()
         self.norm_w = W("norm").contiguous()
-        self.lm_head = self.embed if tied else W("lm_head").contiguous()
+        self._lm_head, self._lm_kt = (self.embed if tied else W("lm_head").contiguous()), None
         if tied and consume_weights:
             weights.pop("lm_head", None)
         self.layers: List[dict] = []
@@ -135,7 +135,7 @@ class StepEngine:
         # hand-written weight-streaming GEMM (split-K partials consumed by the fused glue kernels) for steps of
         # <= 256 tokens; every (N, K, row class) is timed against the library GEMM once and the faster one is kept
         self.custom_gemm = dt != torch.float32 and os.environ.get("LADE_GEMM", "1") != "0" and self.d % 16 == 0 and self.hidden % 64 == 0 and self.inter % 64 == 0
-        self.ktile, self.ktile_bytes = False, 0
+        self.ktile, self.ktile_only, self.ktile_bytes = False, False, 0
         self._build_ktile_copies()
         self._alloc_cache(self.S_max)
         self.attn_events = None             # set to a list to collect (start, end, T, n_splits) hipEvent pairs per layer
@@ -160,38 +160,73 @@ class StepEngine:
     KTILE_RESERVE = 24 << 30             # HBM left free for the KV cache, workspaces and the library's own buffers when the copies are made
 
     def _build_ktile_copies(self) -> None:
-        """A second, K-TILE-MAJOR copy ([K/64][N][64], `lade_weight_to_ktile`) of every projection weight for the skinny GEMM: the 128-byte
-        segments of all rows of one K tile are contiguous, so a work-group's tile is one contiguous read and the work-groups of a split
-        sweep memory linearly (7B projections at 60 rows: 88.8 -> 79.2 us per layer, bit-identical results).  The row-major
-        weights stay for the library GEMM (prefill chunks, steps wider than 256 rows).  This spends HBM to buy bandwidth - 13 GB more at
-        7B, 26 GB at 13B of the 288 GB - and is skipped when the copies would not fit (Llama-2-70B in bf16 keeps the row-major path).
-        LADE_W_KTILE=0 / 1 overrides the decision."""
+        """K-TILE-MAJOR projection weights ([K/64][N][64], `lade_weight_to_ktile`) for the skinny GEMM: the 128-byte segments of all rows of
+        one K tile are contiguous, so a work-group's tile is one contiguous read and the work-groups of a split sweep memory linearly
+        (7B projections at 60 rows: 88.8 -> 79.2 us per layer, 70B: 296.5 -> 261.4, bit-identical results).
+          * "dual" (it fits: 13 GB more at 7B, 26 GB at 13B of the 288 GB): a second copy; the row-major weights stay for the library
+            GEMM (prefill chunks, steps wider than 256 rows) - HBM spent to buy bandwidth;
+          * "only" (a model that cannot be held twice: Llama-2-70B in bf16): the weights are converted one by one and the row-major
+            originals released; the library GEMM of a wide step gets its row-major operand from `lade_weight_from_ktile` into one
+            scratch per projection (prefill pays one extra pass over the weights per chunk, decode steps gain ~12 %).
+        LADE_W_KTILE = 0 | 1 (dual) | only overrides the decision."""
         want = os.environ.get("LADE_W_KTILE", "auto")
         if not self.custom_gemm or want == "0":
             return
-        extra = sum(lw[n].numel() * lw[n].element_size() for lw in self.layers for n in self.GEMM_NAMES)
-        if want != "1":
+        extra = sum(lw[n].numel() * lw[n].element_size() for lw in self.layers for n in self.LAYER_GEMMS)
+        only = want == "only"
+        if want == "auto":
             free, _total = torch.cuda.mem_get_info(self.device)
-            if free < extra + self.KTILE_RESERVE:
-                return
+            only = free < extra + self.KTILE_RESERVE
         with torch.cuda.device(self.device):            # the C ABI launches on the current device's current stream
+            if only:
+                # one scratch per projection for the library GEMM's row-major operand, allocated before the conversion frees anything
+                self._row_scratch = {n: torch.empty_like(self.layers[0][n]) for n in self.LAYER_GEMMS}
             for lw in self.layers:
-                for n in self.GEMM_NAMES:
+                for n in self.LAYER_GEMMS:
                     lw[n + "_kt"] = ops.to_ktile(lw[n])
-        self.ktile = True
-        self.ktile_bytes = extra
+                    if only:
+                        del lw[n]                       # the allocator hands the block to the next conversion
+        self.ktile, self.ktile_only = True, only
+        self.ktile_bytes = (0 if only else extra) + self._lm_head.numel() * self._lm_head.element_size()
+        self.lm_head = self._lm_head                 # builds its copy (the output projection is small: always held in both layouts)
+
+    @property
+    def lm_head(self) -> torch.Tensor:
+        return self._lm_head
+
+    @lm_head.setter
+    def lm_head(self, w: torch.Tensor) -> None:
+        """Replaces the output projection (bench / tests build successor-map and tied models on a live engine).  The K-tile-major copy
+        the step's lm_head GEMM streams is rebuilt here; in-place edits of `w` made AFTER the assignment are not seen by the copy -
+        assign again."""
+        self._lm_head = w
+        self._lm_kt = None
+        if self.ktile and w.dim() == 2 and w.stride(1) == 1 and w.shape[1] % 64 == 0:
+            with torch.cuda.device(self.device):
+                self._lm_kt = ops.to_ktile(w)
 
     def zero_projections(self, names: Sequence[str]) -> None:
         """bench / tests (successor-map models): zero the named projections of every layer in every layout the engine holds"""
         for lw in self.layers:
             for n in names:
-                lw[n].zero_()
-                if n + "_kt" in lw:
-                    lw[n + "_kt"].zero_()
+                for k in (n, n + "_kt"):
+                    if k in lw:
+                        lw[k].zero_()
 
     def _w(self, lw: dict, name: str) -> torch.Tensor:
         """the weight the skinny GEMM streams: the K-tile-major copy when the engine holds one"""
         return lw[name + "_kt"] if self.ktile else lw[name]
+
+    def _row(self, lw: dict, name: str) -> torch.Tensor:
+        """the row-major weight a library GEMM takes; K-tile-only engines rebuild it into the projection's scratch (same stream: ordered
+        before the GEMM that reads it and after the previous layer's)"""
+        w = lw.get(name)
+        return w if w is not None else ops.from_ktile(lw[name + "_kt"], out=self._row_scratch[name])
+
+    @staticmethod
+    def _nk(w: torch.Tensor):
+        """(N, K) of a projection weight in either layout"""
+        return (w.shape[1], w.shape[0] * 64) if w.dim() == 3 else (w.shape[0], w.shape[1])
 
     def _alloc_cache(self, S_max: int, keep_rows: int = 0) -> None:
         """KV cache [L][2][Hkv*S_max*d] (K: [Hkv][S_max][d], V: [Hkv][d][S_max]), zero-initialised; RoPE tables for it.
@@ -275,15 +310,17 @@ class StepEngine:
         key = (name, mclass)
         if key in self.gemm_cfg:
             return self.gemm_cfg[key]
-        ws = [lw[name] for lw in self.layers]
-        N, K = ws[0].shape
-        ws = (ws, [self._w(lw, name) for lw in self.layers])       # (row-major: library GEMM, what the skinny GEMM streams)
+        if name == "lm_head":
+            ws = ([self._lm_head], [self._lm_kt if self._lm_kt is not None else self._lm_head])
+        else:         # (row-major: library GEMM - none when the weights are held K-tile-major only, what the skinny GEMM streams)
+            ws = (None if self.ktile_only else [lw[name] for lw in self.layers], [self._w(lw, name) for lw in self.layers])
+        N, K = self._nk(ws[1][0])
         # one decision per (shape, row class, dtype) and process: engines of the same model (lookahead-parallel ranks run as
         # threads, a decoder rebuilt on the same weights) must pick the same kernel, or their 16-bit results round differently
         # (the gate/up decision differs from a plain projection of the same shape - SwiGLU tail cost, fused-epilogue variant - and
         # timings taken on one GPU model do not transfer to another)
         gkey = (int(N), int(K), mclass, str(self.dtype), name == "wgu", self.gu_layout if name == "wgu" else 0,
-                torch.cuda.get_device_name(self.device), self.n_cu, self.ktile)
+                torch.cuda.get_device_name(self.device), self.n_cu, ws[1][0].dim() == 3, name == "lm_head")
         with _TUNE_LOCK:
             if gkey in _TUNE_CACHE:
                 self.gemm_cfg[key] = _TUNE_CACHE[gkey]
@@ -297,6 +334,8 @@ class StepEngine:
         ws_lib, ws = ws
         a = torch.randn({32: 30, 64: 60, 96: 92, 128: 128, 192: 180, 256: 240}[mclass], K, device=self.device).to(self.dtype)
         out = torch.empty(a.shape[0], N, dtype=self.dtype, device=self.device)
+        if name == "lm_head":
+            return self._tune_lm_head(mclass, a, out, ws_lib, ws, N, K)
         cands = []
         # (m-blocks per work-group, m-blocks per wave, n-tiles per wave (0 = fewest), weight rows per work-group)
         shapes = {32: ((1, 1, 0, (64, 128, 256)), (1, 1, 2, (128, 256)), (2, 1, 0, (128,)), (1, 1, 1, (96,))),
@@ -339,7 +378,11 @@ class StepEngine:
         tail = (lambda out_bytes: 0.0025 + out_bytes / 4e9) if name == "wgu" else (lambda out_bytes: 0.0)
         if name == "wgu" and os.environ.get("LADE_GU_TAIL_FIXED"):          # experiment: the flat 6 us estimate
             tail = lambda out_bytes: 0.006
-        t_lib = time_it(lambda i: torch.matmul(a, ws_lib[i % len(ws_lib)].t(), out=out)) + 0.003 + tail(Mrows * N * 2)      # + the consumer's extra read
+        if name != "wgu" and os.environ.get("LADE_TUNE_CONSUMER"):          # experiment: the consumer's read of the partials, every projection
+            rate = float(os.environ["LADE_TUNE_CONSUMER"]) * 1e9
+            tail = lambda out_bytes: out_bytes / rate
+        # + the consumer's extra read; K-tile-only weights: the library would need its row-major operand rebuilt per call - not a candidate
+        t_lib = float("inf") if ws_lib is None else time_it(lambda i: torch.matmul(a, ws_lib[i % len(ws_lib)].t(), out=out)) + 0.003 + tail(Mrows * N * 2)
         timed = []                        # (ms incl. the consumer tail, (mb, bn, S, mt, nt))
         for (mb, bn, S, mt, nt) in cands:
             t = time_it(lambda i: ops.gemm_parts(a, ws[i % len(ws)], self.ws_part, S, bn, mb, mt, nt)) + tail(S * Mrows * N * 4)
@@ -363,13 +406,56 @@ class StepEngine:
         if timed and min(timed)[0] < t_lib:
             t_best, best = min(timed)
         if os.environ.get("LADE_TUNE_VERBOSE"):          # tools/gemm_tune_probe.py: what the tuner saw
-            mbytes = N * K * ws_lib[0].element_size() / 1e6
+            mbytes = N * K * ws[0].element_size() / 1e6
             top = " ".join(f"{c}:{t * 1e3:.1f}" for t, c in sorted(timed)[:6])
             print(f"[tune] {name}:{mclass} rows={Mrows} N={N} K={K} lib {t_lib * 1e3:.1f} us | best {best} {t_best * 1e3:.1f} us "
                   f"({mbytes / (t_best * 1e3):.2f} TB/s) | {top}", file=sys.stderr, flush=True)
         return best
 
-    GEMM_NAMES = ("wqkv", "wo", "wgu", "wd")
+    def _tune_lm_head(self, mclass: int, a, out, ws_lib, ws, N: int, K: int):
+        """lm_head on the rows that are read (1 for plain decoding, 1 + W + g gs for a lookahead step): the skinny GEMM WITHOUT split-K -
+        N / bn work-groups cover the CUs on their own at vocabulary sizes, the output is written once in the model dtype - against
+        the library.  Measured at V = 32000, K = 4096, 16 rows: library 57.3 us, skinny on row-major weights 48.3 us, on the K-tile-major
+        copy 39.4 us (6.65 TB/s; `profiles/r3_lm_head_probe.txt`)."""
+        mbs = {32: 1, 64: 2, 96: 3, 128: 4, 192: 6, 256: 8}[mclass]
+
+        def time_it(fn, reps=12):
+            best_t = float("inf")
+            for rnd in range(2):
+                fn()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                best_t = min(best_t, e0.elapsed_time(e1) / reps)
+            return best_t
+
+        t_lib = time_it(lambda: torch.matmul(a, ws_lib[0].t(), out=out))
+        timed = []
+        for bn in (64, 96, 128, 192, 256):
+            for mt in sorted({1, mbs if mbs <= 4 else mbs // 2}):
+                for nt in (0, 1, 2):
+                    if mbs % mt:
+                        continue
+                    try:
+                        t = time_it(lambda: ops.gemm_skinny(a, ws[0], out=out, n_split=1, bn=bn, mb=mbs, mt=mt, nt=nt))
+                    except cabi.LadeHipError:
+                        continue                      # wave grid not built for this row class
+                    timed.append((t, (mbs, bn, 1, mt, nt)))
+        best, t_best = None, t_lib
+        if timed and min(timed)[0] < t_lib:
+            t_best, best = min(timed)
+        if os.environ.get("LADE_TUNE_VERBOSE"):
+            top = " ".join(f"{c}:{t * 1e3:.1f}" for t, c in sorted(timed)[:4])
+            print(f"[tune] lm_head:{mclass} rows={a.shape[0]} N={N} K={K} lib {t_lib * 1e3:.1f} us | best {best} {t_best * 1e3:.1f} us "
+                  f"({N * K * 2 / 1e6 / (t_best * 1e3):.2f} TB/s) | {top}", file=sys.stderr, flush=True)
+        return best
+
+    LAYER_GEMMS = ("wqkv", "wo", "wgu", "wd")
+    GEMM_NAMES = LAYER_GEMMS + ("lm_head",)
     ROW_CLASSES = (32, 64, 96, 128, 192, 256)
 
     def tune_all(self) -> dict:
@@ -420,7 +506,7 @@ class StepEngine:
                 ops.rope_kv_append_parts(part, cfg_qkv[2], qb, pos, self.cos, self.sin, self.k_cache(li), self.vt_cache(li), T, P, H=H, Hkv=Hkv, d=d, dyn_P=dyn_P)
                 q_in = qb
             else:
-                torch.matmul(h, lw["wqkv"].t(), out=qkv)
+                torch.matmul(h, self._row(lw, "wqkv").t(), out=qkv)
                 ops.rope_kv_append(qkv, pos, self.cos, self.sin, self.k_cache(li), self.vt_cache(li), P, H=H, Hkv=Hkv, d=d, dyn_P=dyn_P)
                 q_in = qkv
             ev = None if self.skip_attn else self.attn_events      # skip_attn: `o` keeps stale values, the logits are meaningless
@@ -443,7 +529,7 @@ class StepEngine:
                 ops.gemm_parts(o, self._w(lw, "wo"), part, cfg_o[2], cfg_o[1], cfg_o[0], cfg_o[3], cfg_o[4])
                 ops.add_rmsnorm_parts(x, part, cfg_o[2], lw["ln2"], self.eps, out=h)      # x += attn; h = norm(x)
             else:
-                torch.matmul(o, lw["wo"].t(), out=r)
+                torch.matmul(o, self._row(lw, "wo").t(), out=r)
                 ops.add_rmsnorm(x, r, lw["ln2"], self.eps, out=h)
             if cfg_gu and cfg_gu[2] == 1:                 # gate/up GEMM + SwiGLU in one launch
                 ops.gemm_swiglu(h, self._w(lw, "wgu"), a, cfg_gu[1], cfg_gu[0], cfg_gu[3], cfg_gu[4])
@@ -451,13 +537,13 @@ class StepEngine:
                 ops.gemm_parts(h, self._w(lw, "wgu"), part, cfg_gu[2], cfg_gu[1], cfg_gu[0], cfg_gu[3], cfg_gu[4])
                 ops.silu_mul_parts(part, cfg_gu[2], T, self.inter, out=a, layout=self.gu_layout)
             else:
-                torch.matmul(h, lw["wgu"].t(), out=gu)
+                torch.matmul(h, self._row(lw, "wgu").t(), out=gu)
                 ops.silu_mul(gu, out=a, layout=self.gu_layout)
             if cfg_d:
                 ops.gemm_parts(a, self._w(lw, "wd"), part, cfg_d[2], cfg_d[1], cfg_d[0], cfg_d[3], cfg_d[4])
                 r_parts = cfg_d[2]
             else:
-                torch.matmul(a, lw["wd"].t(), out=r)
+                torch.matmul(a, self._row(lw, "wd").t(), out=r)
                 r_parts = 0
         if n_sel == 0:                                             # cache-filling chunk of a long prefill
             return None
@@ -466,7 +552,12 @@ class StepEngine:
             hn = ops.add_rmsnorm_rows(x, sel_rows, n_sel, self.norm_w, self.eps, part=part, n_parts=r_parts)
         else:
             hn = ops.add_rmsnorm_rows(x, sel_rows, n_sel, self.norm_w, self.eps, r=r)
-        return torch.matmul(hn, self.lm_head.t())
+        cfg_lm = self._tune("lm_head", n_sel) if (self.custom_gemm and n_sel <= self.ROW_CLASSES[-1] and self.V % 8 == 0) else None
+        if cfg_lm:
+            logits = torch.empty(n_sel, self.V, dtype=self.dtype, device=self.device)
+            return ops.gemm_skinny(hn, self._lm_kt if self._lm_kt is not None else self._lm_head, out=logits, n_split=1,
+                                   bn=cfg_lm[1], mb=cfg_lm[0], mt=cfg_lm[3], nt=cfg_lm[4])
+        return torch.matmul(hn, self._lm_head.t())
 
     # ---- prefill: plain causal rows over the growing cache ---------------------------------------------
     @torch.no_grad()

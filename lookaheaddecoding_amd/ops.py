@@ -276,6 +276,17 @@ def to_ktile(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def from_ktile(wkt: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """K-tile-major [K/64, N, 64] -> row-major [N, K] (`lade_weight_from_ktile`), into `out` when given (a reused scratch)"""
+    KT, N, _ = wkt.shape
+    assert wkt.is_contiguous() and wkt.shape[2] == 64
+    if out is None:
+        out = torch.empty(N, KT * 64, dtype=wkt.dtype, device=wkt.device)
+    assert out.shape == (N, KT * 64) and out.stride(1) == 1 and out.dtype == wkt.dtype
+    call("lade_weight_from_ktile", ptr(wkt), ptr(out), out.stride(0), N, KT * 64, dtype_code(wkt))
+    return out
+
+
 def _gemm(a: torch.Tensor, w: torch.Tensor, c, ldc: int, part, n_split: int, bn: int, mb: int, mt: int, nt: int, epilogue: int) -> None:
     M, K = a.shape
     assert a.stride(1) == 1

@@ -18,6 +18,10 @@ def test_weight_to_ktile_is_the_permutation_and_refuses_bad_shapes():
         for (N, K) in ((160, 320), (8, 64), (1000, 192), (4096, 11008)):
             w = torch.randn(N, K, device="cuda").to(dtype)
             assert torch.equal(ops.to_ktile(w), w.view(N, K // 64, 64).permute(1, 0, 2).contiguous()), (N, K, dtype)
+            assert torch.equal(ops.from_ktile(ops.to_ktile(w)), w)                    # and back
+            scratch = torch.full((N, K + 64), 7.0, dtype=dtype, device="cuda")        # into a wider scratch: the padding is not touched
+            ops.from_ktile(ops.to_ktile(w), out=scratch[:, :K])
+            assert torch.equal(scratch[:, :K], w) and bool((scratch[:, K:] == 7.0).all())
         w = torch.randn(96, 256, device="cuda").to(dtype)[:, :192]                  # a row stride larger than K
         assert torch.equal(ops.to_ktile(w), w.reshape(96, 3, 64).permute(1, 0, 2).contiguous())
     w = torch.randn(32, 96, device="cuda").bfloat16()
@@ -95,7 +99,7 @@ def test_engine_with_and_without_the_ktile_copy_gives_the_same_logits_bit_for_bi
     w = {k: torch.as_tensor(v) for k, v in random_weights_numpy(cfg, seed=4, std=0.05).items()}
     e0 = _engine(monkeypatch, "0", cfg, w)
     e1 = _engine(monkeypatch, "1", cfg, w)
-    assert not e0.ktile and e1.ktile and all(n + "_kt" in lw for lw in e1.layers for n in e1.GEMM_NAMES)
+    assert not e0.ktile and e1.ktile and all(n + "_kt" in lw for lw in e1.layers for n in e1.LAYER_GEMMS)
     assert not any(k.endswith("_kt") for lw in e0.layers for k in lw)
     e1.adopt_gemm_cfg(e0.tune_all())
     g = torch.Generator().manual_seed(5)
@@ -113,19 +117,71 @@ def test_engine_with_and_without_the_ktile_copy_gives_the_same_logits_bit_for_bi
             outs.append((lg.clone(), e.k_cache(0)[:, P:P + T].clone(), e.vt_cache(cfg["layers"] - 1)[:, :, P:P + T].clone()))
         for x, y in zip(*outs):
             assert torch.isfinite(x.float()).all() and torch.equal(x, y), T
+    # a replaced output projection reaches the copy the step streams
+    before = outs[1][0]
+    head = (torch.randn(cfg["vocab"], cfg["hidden"], generator=g) * 0.05).to(torch.bfloat16).cuda()
+    res = []
+    for e in (e0, e1):
+        e.lm_head = head
+        e.reset()
+        e.prefill(prompt, rows=[P - 1])
+        res.append(e.forward(ids, pos, ops.StepMask(T=T, P=P, is_prefill=True), sel, T).clone())
+    assert torch.equal(res[0], res[1]) and not torch.equal(res[1], before)
+    assert e1._lm_kt is not None and torch.equal(e1._lm_kt, ops.to_ktile(head)) and e0._lm_kt is None
     e1.zero_projections(("wo", "wd"))
     assert all(float(lw[n].abs().sum()) == 0.0 for lw in e1.layers for n in ("wo", "wd", "wo_kt", "wd_kt"))
     assert all(float(lw["wqkv_kt"].abs().sum()) > 0.0 for lw in e1.layers)
 
 
-def test_ktile_copy_is_made_when_it_fits_and_skipped_when_it_does_not(monkeypatch):
+def test_engine_holding_the_weights_ktile_only_gives_the_same_logits_and_prefills_through_the_library(monkeypatch):
+    """LADE_W_KTILE=only (what a model too large to be held twice gets): no row-major projection weights are kept; decode-width steps are
+    bit-identical to the row-major engine on the same GEMM configurations, and a prefill chunk wider than 256 rows - library GEMM on the
+    row-major operand rebuilt by lade_weight_from_ktile - is bit-identical too"""
+    from lookaheaddecoding_amd import ops
+    cfg = make_config("tiny-d128", max_pos=1024)
+    w = {k: torch.as_tensor(v) for k, v in random_weights_numpy(cfg, seed=6, std=0.05).items()}
+    from lookaheaddecoding_amd.engine import StepEngine
+    monkeypatch.setenv("LADE_W_KTILE", "0")
+    e0 = StepEngine(cfg, w, dtype=torch.bfloat16, max_seq=1024, max_T=512)
+    monkeypatch.setenv("LADE_W_KTILE", "only")
+    e2 = StepEngine(cfg, w, dtype=torch.bfloat16, max_seq=1024, max_T=512)
+    assert e2.ktile and e2.ktile_only and not any(n in lw for lw in e2.layers for n in e2.LAYER_GEMMS)
+    assert all(n + "_kt" in lw for lw in e2.layers for n in e2.LAYER_GEMMS)
+    e2.adopt_gemm_cfg(e0.tune_all())
+    g = torch.Generator().manual_seed(7)
+    prompt = torch.randint(3, cfg["vocab"], (300,), generator=g).tolist()           # one causal chunk of 300 rows: wider than the skinny GEMM takes
+    P, T = len(prompt), 60
+    ids = torch.randint(3, cfg["vocab"], (T,), generator=g).to(torch.int32).cuda()
+    pos = (P + torch.arange(T)).to(torch.int32).cuda()
+    sel = torch.arange(T, dtype=torch.int32).cuda()
+    outs = []
+    for e in (e0, e2):
+        lg_p, done = e.prefill(prompt, rows=[P - 2, P - 1])
+        assert done == 0
+        lg = e.forward(ids, pos, ops.StepMask(T=T, P=P, is_prefill=True), sel, T)
+        outs.append((lg_p.clone(), lg.clone(), e.k_cache(1)[:, :P + T].clone()))
+    for x, y in zip(*outs):
+        assert torch.isfinite(x.float()).all() and torch.equal(x, y)
+    # its own autotune never picks the library for a decode-width step (there is no row-major operand to give it)
+    monkeypatch.setenv("LADE_W_KTILE", "only")
+    e3 = StepEngine(cfg, w, dtype=torch.bfloat16, max_seq=1024, max_T=512)
+    e3.prefill(prompt[:40], rows=[39])
+    lg3 = e3.forward(ids, (40 + torch.arange(T)).to(torch.int32).cuda(), ops.StepMask(T=T, P=40, is_prefill=True), sel, T)
+    assert torch.isfinite(lg3.float()).all()
+    e2.zero_projections(("wo", "wd"))
+    assert all(float(lw[n + "_kt"].abs().sum()) == 0.0 for lw in e2.layers for n in ("wo", "wd"))
+
+
+def test_ktile_layout_decision_dual_when_it_fits_only_when_it_does_not(monkeypatch):
     from lookaheaddecoding_amd.engine import StepEngine
     cfg = make_config("tiny-d128", max_pos=512)
     w = {k: torch.as_tensor(v) for k, v in random_weights_numpy(cfg, seed=4, std=0.05).items()}
     e = _engine(monkeypatch, "auto", cfg, w)
-    assert e.ktile and e.ktile_bytes == sum(lw[n].numel() * 2 for lw in e.layers for n in e.GEMM_NAMES)
-    monkeypatch.setattr(StepEngine, "KTILE_RESERVE", 1 << 50)                      # "the copies do not fit": row-major path, as Llama-2-70B
+    assert e.ktile and e.ktile_bytes == sum(lw[n].numel() * 2 for lw in e.layers for n in e.LAYER_GEMMS) + e.lm_head.numel() * 2
+    monkeypatch.setattr(StepEngine, "KTILE_RESERVE", 1 << 50)                      # "a second copy does not fit" (Llama-2-70B): K-tile-major only
     e = _engine(monkeypatch, "auto", cfg, w)
-    assert not e.ktile and e.ktile_bytes == 0
+    assert e.ktile and e.ktile_only and e.ktile_bytes == e.lm_head.numel() * 2
+    e = _engine(monkeypatch, "0", cfg, w)
+    assert not e.ktile and e.ktile_bytes == 0 and all(n in lw for lw in e.layers for n in e.LAYER_GEMMS)
     e = StepEngine(cfg, w, dtype=torch.float32, max_seq=256, max_T=64)              # fp32 has no skinny GEMM: nothing to copy
     assert not e.ktile

@@ -12,7 +12,7 @@ from lookaheaddecoding_amd import ops
 
 MODEL = sys.argv[1] if len(sys.argv) > 1 else "7b"
 MS = [int(x) for x in sys.argv[2:]] or [60]
-HID, INTER, QKV = {"7b": (4096, 11008, 12288), "13b": (5120, 13824, 15360)}[MODEL]
+HID, INTER, QKV = {"7b": (4096, 11008, 12288), "13b": (5120, 13824, 15360), "70b": (8192, 28672, 10240)}[MODEL]
 N_CU = torch.cuda.get_device_properties(0).multi_processor_count
 SHAPES = {32: ((1, 1, 0, (64, 128, 256)), (1, 1, 2, (128, 256)), (2, 1, 0, (128,)), (1, 1, 1, (96,))),
           64: ((2, 1, 0, (128, 256)), (2, 2, 0, (128, 192, 256)), (2, 2, 2, (192, 256)), (2, 1, 1, (64, 96)), (2, 2, 1, (96,))),
@@ -43,7 +43,7 @@ def candidates(N, K, mclass, swiglu):
     out = []
     if swiglu:
         mbs = mclass // 32
-        for bn in (64, 96, 128):
+        for bn in (64, 96, 128) + ((224,) if N % 224 == 0 else ()):
             for mt in sorted({1, 2 if mbs % 2 == 0 else 1, mbs}):
                 if mbs % mt == 0 and (mbs // mt) * (bn // 32) <= 8:
                     out.append((mbs, bn, 1, mt, 1))
