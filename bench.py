@@ -250,7 +250,7 @@ def worker(args):
         cfg["layers"] = args.layers
     W, N, G = c["W"], c["N"], c["G"]
     gs = N - 1
-    GD_PAIRS = 3                                                   # with / without-attention block pairs of the step-time difference
+    GD_PAIRS = 5                                                   # with / without-attention block pairs of the step-time difference
     total_steps = (N - 1) + args.warmup + args.steps * (max(1, args.blocks) + GD_PAIRS) + 16
     max_seq = args.prompt_len + total_steps * N + (N - 1) * (W + G) + 64
     cfg["max_pos"] = max(cfg.get("max_pos", 4096), max_seq)
@@ -381,11 +381,20 @@ def worker(args):
     # same hipGraph mode, same shapes (random weights: no candidates either way) - independent of the host's launch rate
     graph_delta = None
     if extras and not args.no_graph:
-        eng.skip_attn = True
-        d2 = LookaheadDecoder(eng, W, N, 0, use_graph=True)      # no candidates: the garbage logits must not change the step shape
-        d2.start(prompt, rng=random.Random(1))
-        for _ in range(N - 1 + args.warmup):
-            d2.step()
+        # two decoders WITHOUT candidates (G = 0: whatever the logits are, the step keeps its shape), one with the attention launches and one
+        # without, over the same engine.  They share the KV cache, so each overwrites the other's rows - the values are meaningless from
+        # here on, the launches, shapes and bytes are those of the timed run (T = (N-1) W rows, the same cache length)
+        def warmed(skip):
+            eng.skip_attn = skip
+            d = LookaheadDecoder(eng, W, N, 0, use_graph=True)
+            d.start(prompt, rng=random.Random(1))
+            for _ in range(N - 1 + args.warmup):
+                d.step()
+            sync()
+            eng.skip_attn = False
+            return d
+
+        d1, d2 = warmed(False), warmed(True)
         # blocks of K steps with and without the attention launches in ALTERNATION, the difference taken pair by pair (median): the
         # boxes drift by a few per cent within a run, and 3 % of a 4 ms step is 4 us per layer - as much as the quantity measured when
         # the two blocks are taken minutes apart
@@ -400,7 +409,7 @@ def worker(args):
 
         pairs, i2, i1 = [], [], []
         for _ in range(GD_PAIRS):
-            ms_with, inf_w = block(run, False)
+            ms_with, inf_w = block(d1, False)
             ms_without, inf_n = block(d2, True)
             pairs.append((ms_with, ms_without))
             i1 += inf_w

@@ -7,7 +7,7 @@ from conftest import ROOT
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    with open(os.path.join(ROOT, "profiles", "r2_bench.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r3_bench.json")) as f:
         line = [l for l in f.read().splitlines() if l.strip().startswith("{")][-1]
     d = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
@@ -38,7 +38,7 @@ def test_step_stream_bytes_model_and_the_committed_figure():
     kv = 2 * 32 * 2091 * 128 * 2
     assert bench.step_stream_bytes(cfg, 2091, 1) == 32 * (per_layer + kv) + 32000 * 4096 * 2
     assert bench.step_stream_bytes(cfg, 2091, 0) == 32 * (per_layer + kv)
-    with open(os.path.join(ROOT, "profiles", "r2_bench.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r3_bench.json")) as f:
         d = json.loads([l for l in f.read().splitlines() if l.strip().startswith("{")][-1])
     s = d["step_stream"]
     assert s["bound"] == "hbm" and s["unit"] == "GB/s" and s["peak"] == 8000.0
