@@ -176,7 +176,11 @@ class StepEngine:
         only = want == "only"
         if want == "auto":
             free, _total = torch.cuda.mem_get_info(self.device)
-            only = free < extra + self.KTILE_RESERVE
+            # what is allocated after this: the KV cache and the step workspaces of the configured sizes, + a fixed reserve for the
+            # library's workspaces, the n-gram pool and growth
+            esz = self.layers[0]["wo"].element_size()
+            later = 2 * self.L * self.Hkv * self.S_max * self.d * esz + 16 * 128 * max((self.H + 2 * self.Hkv) * self.d, 2 * self.inter) * 4
+            only = free < extra + later + self.KTILE_RESERVE
         with torch.cuda.device(self.device):            # the C ABI launches on the current device's current stream
             if only:
                 # one scratch per projection for the library GEMM's row-major operand, allocated before the conversion frees anything
