@@ -324,7 +324,7 @@ class StepEngine:
         # (the gate/up decision differs from a plain projection of the same shape - SwiGLU tail cost, fused-epilogue variant - and
         # timings taken on one GPU model do not transfer to another)
         gkey = (int(N), int(K), mclass, str(self.dtype), name == "wgu", self.gu_layout if name == "wgu" else 0,
-                torch.cuda.get_device_name(self.device), self.n_cu, ws[1][0].dim() == 3, name == "lm_head")
+                torch.cuda.get_device_name(self.device), self.n_cu, ws[1][0].dim() == 3, ws[0] is None, name == "lm_head")
         with _TUNE_LOCK:
             if gkey in _TUNE_CACHE:
                 self.gemm_cfg[key] = _TUNE_CACHE[gkey]
