@@ -31,4 +31,12 @@ python tools/attn_bench.py --T 60 120 --P 128 512 1024 2048 4096 --splits 0 > $O
 python tools/attn_in_step.py --T 60 120 --splits 0 > $OUT/attn_in_step.txt 2>&1
 python tools/attn_in_step.py --model codellama-13b --layers 6 --T 120 --splits 0 >> $OUT/attn_in_step.txt 2>&1
 cat $OUT/attn_in_step.txt
+# 5. weight layout probes (row-major against K-tile-major): only with PROBES=1 (another ~1 min)
+if [ "${PROBES:-0}" = 1 ]; then
+    python tools/gemm_ktile_probe.py 7b 60 30 120 > $OUT/gemm_ktile_probe.txt 2>&1
+    python tools/gemm_ktile_probe.py 13b 120 >> $OUT/gemm_ktile_probe.txt 2>&1
+    python tools/gemm_ktile_probe.py 70b 60 30 > $OUT/gemm_ktile_probe_70b.txt 2>&1
+    python tools/lm_head_probe.py > $OUT/lm_head_probe.txt 2>&1
+    grep -h "layer sum\|rows=" $OUT/gemm_ktile_probe.txt $OUT/gemm_ktile_probe_70b.txt $OUT/lm_head_probe.txt
+fi
 ls -la $OUT | head -60
