@@ -599,6 +599,21 @@ def worker(args):
                             "note": "per rank; unavoidable reads of one decode step (every projection weight, the K/V cache, the lm_head) / ms_per_step"},
             "cpu_baseline": cpu,
         }
+        # the projections of a step as the engine's autotune timed the kernels it chose (isolated launches, every launch on another layer's
+        # weights; not the in-step time - the kernel trace under profiles/ has that): weight bytes / time against the same HBM peak
+        cls_T = next((c_ for c_ in eng.ROW_CLASSES if int(round(avg_T)) <= c_), None)
+        proj = {}
+        for nm in eng.LAYER_GEMMS:
+            tm = eng.gemm_times.get((nm, cls_T))
+            if tm and tm[0]:
+                proj[nm] = {"us": round(tm[0] * 1e3, 2), "weight_mb": round(tm[1] / 1e6, 1), "tb_per_s": round(tm[1] / tm[0] / 1e9, 2),
+                            "frac_of_8_tb_per_s": round(tm[1] / tm[0] / 1e9 / 8.0, 3), "kernel": eng.gemm_cfg.get((nm, cls_T)) or "library"}
+        if proj:
+            tot_us, tot_b = sum(v["us"] for v in proj.values()), sum(eng.gemm_times[(nm, cls_T)][1] for nm in proj)
+            out["projections"] = {"row_class": cls_T, "weight_layout": "k-tile-major" if eng.ktile else "row-major", **proj,
+                                  "layer_sum_us": round(tot_us, 2), "layer_tb_per_s": round(tot_b / tot_us / 1e6, 2),
+                                  "note": "per layer, as timed by the engine's autotune for the kernels it chose (mb, bn, n_split, mt, nt); gate/up includes SwiGLU "
+                                          "(fused epilogue when n_split = 1, else + the tuner's estimate of the SwiGLU kernel)"}
     if use_lp:
         dist.barrier()
         dist.destroy_process_group()

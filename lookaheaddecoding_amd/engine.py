@@ -84,6 +84,7 @@ def _on_device(fn):
 
 
 _TUNE_CACHE: dict = {}
+_TUNE_TIMES: dict = {}
 _TUNE_LOCK = __import__("threading").Lock()
 
 
@@ -143,6 +144,7 @@ class StepEngine:
         self.skip_attn = False              # bench.py only: leave the attention launches out (step-time difference = their cost)
         self.max_splits = 32
         self.gemm_cfg = {}
+        self.gemm_times = {}                # (projection, row class) -> (ms of the chosen kernel in the autotune, weight bytes)
         self._alloc_workspaces(max_T)
         try:
             self.n_cu = torch.cuda.get_device_properties(self.device.index).multi_processor_count
@@ -326,11 +328,13 @@ class StepEngine:
         gkey = (int(N), int(K), mclass, str(self.dtype), name == "wgu", self.gu_layout if name == "wgu" else 0,
                 torch.cuda.get_device_name(self.device), self.n_cu, ws[1][0].dim() == 3, ws[0] is None, name == "lm_head")
         with _TUNE_LOCK:
-            if gkey in _TUNE_CACHE:
-                self.gemm_cfg[key] = _TUNE_CACHE[gkey]
-                return self.gemm_cfg[key]
-            best = self._tune_timed(name, mclass, ws, N, K)
-            _TUNE_CACHE[gkey] = best
+            if gkey not in _TUNE_CACHE:
+                self._tuned_ms = None
+                _TUNE_CACHE[gkey] = self._tune_timed(name, mclass, ws, N, K)
+                _TUNE_TIMES[gkey] = self._tuned_ms
+            best = _TUNE_CACHE[gkey]
+            # what the winner took when it was timed (isolated launches, every launch on another layer's weights), for bench.py's report
+            self.gemm_times[key] = (_TUNE_TIMES.get(gkey), int(N) * int(K) * ws[1][0].element_size())
         self.gemm_cfg[key] = best
         return best
 
@@ -409,6 +413,7 @@ class StepEngine:
         best, t_best = None, t_lib
         if timed and min(timed)[0] < t_lib:
             t_best, best = min(timed)
+        self._tuned_ms = t_best
         if os.environ.get("LADE_TUNE_VERBOSE"):          # tools/gemm_tune_probe.py: what the tuner saw
             mbytes = N * K * ws[0].element_size() / 1e6
             top = " ".join(f"{c}:{t * 1e3:.1f}" for t, c in sorted(timed)[:6])
@@ -452,6 +457,7 @@ class StepEngine:
         best, t_best = None, t_lib
         if timed and min(timed)[0] < t_lib:
             t_best, best = min(timed)
+        self._tuned_ms = t_best
         if os.environ.get("LADE_TUNE_VERBOSE"):
             top = " ".join(f"{c}:{t * 1e3:.1f}" for t, c in sorted(timed)[:4])
             print(f"[tune] lm_head:{mclass} rows={a.shape[0]} N={N} K={K} lib {t_lib * 1e3:.1f} us | best {best} {t_best * 1e3:.1f} us "
