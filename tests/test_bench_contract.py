@@ -44,3 +44,20 @@ def test_step_stream_bytes_model_and_the_committed_figure():
     assert s["bound"] == "hbm" and s["unit"] == "GB/s" and s["peak"] == 8000.0
     assert abs(s["achieved"] - s["bytes_per_step"] / (d["ms_per_step"] * 1e-3) / 1e9) / s["achieved"] < 0.01
     assert abs(s["frac"] - s["achieved"] / s["peak"]) < 1e-3 and 0.0 < s["frac"] < 1.0
+
+
+def test_projections_object_of_the_committed_line_is_consistent():
+    """bench.py's `projections` (what the engine's autotune timed for the kernels it chose): weight bytes of the 7B shape, TB/s = bytes / time,
+    the layer sum, and the layout the line says the GEMMs stream"""
+    with open(os.path.join(ROOT, "profiles", "r3_bench_projections.json")) as f:
+        d = json.loads([l for l in f.read().splitlines() if l.strip().startswith("{")][-1])
+    p = d["projections"]
+    assert p["row_class"] == 64 and p["weight_layout"] == "k-tile-major" and "K-tile-major" in d["config"]["weight_layout"]
+    want_mb = {"wqkv": 3 * 4096 * 4096 * 2 / 1e6, "wo": 4096 * 4096 * 2 / 1e6, "wgu": 2 * 11008 * 4096 * 2 / 1e6, "wd": 11008 * 4096 * 2 / 1e6}
+    tot = 0.0
+    for n, mb in want_mb.items():
+        e = p[n]
+        assert abs(e["weight_mb"] - mb) < 0.1 and abs(e["tb_per_s"] - mb / e["us"]) < 0.02 and abs(e["frac_of_8_tb_per_s"] - e["tb_per_s"] / 8.0) < 2e-3
+        assert e["kernel"] == "library" or len(e["kernel"]) == 5
+        tot += e["us"]
+    assert abs(p["layer_sum_us"] - tot) < 0.05 and 0.3 < p["layer_tb_per_s"] / 8.0 < 1.0
