@@ -316,13 +316,16 @@ int lade_gather_rows(const void* src, const int32_t* idx, void* dst, int32_t row
  * order - deterministic - by lade_splitk_reduce).  bn = weight rows per work-group (32..256), mb = 32-row activation
  * blocks per work-group (1: 32 rows, 2: 64, 3: 96, 4: 128, 0: by M; larger M runs as several row blocks).  mt = 32-row activation blocks per WAVE (0 | 1..4, divides
  * mb) and nt = 32-row weight tiles per wave (0 = fewest): the waves form an (mb/mt) x (bn/32/nt) grid; larger wave tiles
- * re-read less from LDS per weight byte.  Unsupported shapes return LADE_E_ARG.  K % 64 == 0.
+ * re-read less from LDS per weight byte.  ring = stages of the LDS ring the tiles arrive in (0 = default: 4 where they fit; 2..8): a
+ * deeper ring keeps more bytes in flight per work-group and leaves room for fewer co-resident work-groups - chosen per projection by the
+ * caller's autotune.  Unsupported shapes return LADE_E_ARG.  K % 64 == 0.  M > 256 runs as several 256-row blocks per launch (bn = 256,
+ * mb = 8, nt = 2 | 4 is a compute-shaped 256 x 256 tile on a double buffer).
  * epilogue (n_split == 1 only): 0 = none; 1 = SwiGLU - W is the fused gate/up weight in the 16-row interleaved order of
  * lade_silu_mul's layout 1 and C is [M][N/2] = silu(gate) * up (the SwiGLU kernel and the fp32 partials of a split-K
  * gate/up GEMM disappear from the step). */
 int lade_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, float* Cpart,
                      int32_t M, int32_t N, int32_t K, int32_t n_split, int32_t bn, int32_t mb, int32_t mt, int32_t nt,
-                     int32_t epilogue, int32_t dtype, void* stream);
+                     int32_t ring, int32_t epilogue, int32_t dtype, void* stream);
 /* The same GEMM on a weight stored K-TILE-MAJOR: Wkt[K/64][N][64], i.e. Wkt[kt][n][j] = W[n][64 kt + j] - the 128-byte segments of all N
  * rows of one 64-deep K tile are contiguous.  Row-major nn.Linear weights (lade/models/modeling_llama.py:360-380, 492-494, 558) make a
  * work-group's K tile BN separate 128-byte reads K elements apart; K-tile-major makes it ONE contiguous BN x 128 bytes, and the
@@ -330,7 +333,7 @@ int lade_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, voi
  * lade_gemm_skinny.  lade_weight_to_ktile builds the copy once at load time (out of place; K % 64 == 0). */
 int lade_gemm_skinny_kt(const void* A, int64_t lda, const void* Wkt, void* C, int64_t ldc, float* Cpart,
                         int32_t M, int32_t N, int32_t K, int32_t n_split, int32_t bn, int32_t mb, int32_t mt, int32_t nt,
-                        int32_t epilogue, int32_t dtype, void* stream);
+                        int32_t ring, int32_t epilogue, int32_t dtype, void* stream);
 int lade_weight_to_ktile(const void* W, int64_t ldw, void* Wkt, int32_t N, int32_t K, int32_t dtype, void* stream);
 /* the inverse, into a caller-provided row-major scratch W[N][ldw]: what a library GEMM needs (prefill chunks wider than 256 rows) when a
  * model too large to be held twice keeps its projection weights K-tile-major only */

@@ -83,8 +83,8 @@ SIGNATURES = {
     "lade_add_rmsnorm_rows": [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp],
     "lade_silu_mul": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "lade_gather_rows": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
-    "lade_gemm_skinny": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
-    "lade_gemm_skinny_kt": [_vp, _i64, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "lade_gemm_skinny": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "lade_gemm_skinny_kt": [_vp, _i64, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "lade_weight_to_ktile": [_vp, _i64, _vp, _i32, _i32, _i32, _vp],
     "lade_weight_from_ktile": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
     "lade_add_rmsnorm_parts": [_vp, _vp, _i32, _i64, _vp, _vp, _i32, _i32, _f32, _i32, _vp],

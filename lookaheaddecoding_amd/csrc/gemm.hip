@@ -60,8 +60,9 @@ using namespace lade;
 // wave (1 | 2 | 3 | 4, divides mb; 0 = 1); nt: 32-row weight tiles per wave (1..4; 0 = spread the tiles over as many n-groups
 // as there are waves).  The waves form an (mb/mt) x (bn/32/nt) grid.  Only the shapes in the table of gemm_kernel.hpp are built.
 static int gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, bool ktile, void* C, int64_t ldc, float* Cpart,
-                       int32_t M, int32_t N, int32_t K, int32_t n_split, int32_t bn, int32_t mb, int32_t mt, int32_t nt,
+                       int32_t M, int32_t N, int32_t K, int32_t n_split, int32_t bn, int32_t mb, int32_t mt, int32_t nt, int32_t ring,
                        int32_t epilogue, int32_t dtype, void* stream) {
+    LADE_REQUIRE(ring == 0 || (ring >= 2 && ring <= 8), LADE_E_ARG, "lade_gemm_skinny: ring=%d (0 = default, 2..8 stages)", ring);
     LADE_REQUIRE(epilogue == 0 || (epilogue == 1 && n_split == 1 && N % 32 == 0 && C != nullptr), LADE_E_ARG,
                  "lade_gemm_skinny: epilogue=%d needs n_split == 1, N %% 32 == 0 and an output matrix", epilogue);
     LADE_REQUIRE(A && W && M > 0 && N > 0 && K > 0 && n_split >= 1, LADE_E_ARG, "lade_gemm_skinny: M=%d N=%d K=%d split=%d", M, N, K, n_split);
@@ -73,7 +74,9 @@ static int gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, b
     if (mt == 0) mt = mb <= 4 ? 1 : mb / 2;
     if (mb > 4 && nt == 0) nt = 1;
     LADE_REQUIRE(mb >= 1 && mb <= 8 && mt >= 1 && mt <= 4 && mb % mt == 0, LADE_E_ARG, "lade_gemm_skinny: mb=%d mt=%d", mb, mt);
-    if (mb > 4 && bn > 128) bn = 128;      // 192 / 256-row work-groups: the activation tile leaves room for <= 128 weight rows per stage
+    // 192 / 256-row work-groups: the activation tile leaves room for <= 128 weight rows per stage of a 3-stage ring; the one wider
+    // shape is the double-buffered 256 x 256 tile (mb = 8, bn = 256, nt = 2 | 4)
+    if (mb > 4 && bn > 128 && !(mb == 8 && bn == 256 && (nt == 2 || nt == 4))) bn = 128;
     const int mw = mb / mt;
     const int tiles = bn <= 32 ? 1 : (bn <= 64 ? 2 : (bn <= 96 ? 3 : (bn <= 128 ? 4 : (bn <= 192 ? 6 : (bn <= 224 ? 7 : 8)))));      // 32-row weight tiles per work-group
     if (nt == 0) {                                     // default: as many n-groups as waves allow
@@ -89,6 +92,7 @@ static int gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, b
     g.w_ts = ktile ? (int64_t)N * G_BK : 0;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("LADE_GEMM_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
     g.epi = epilogue;
+    g.n_stage = ring;
     hipStream_t st = (hipStream_t)stream;
     const int rc = dtype == LADE_BF16 ? gemm_dispatch_bf16(g, st, mw, mt, ng, nt) : gemm_dispatch_f16(g, st, mw, mt, ng, nt);
     if (rc >= 0) return rc;
@@ -97,16 +101,16 @@ static int gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, b
 
 extern "C" int lade_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, float* Cpart,
                                 int32_t M, int32_t N, int32_t K, int32_t n_split, int32_t bn, int32_t mb, int32_t mt, int32_t nt,
-                                int32_t epilogue, int32_t dtype, void* stream) {
-    return gemm_skinny(A, lda, W, ldw, false, C, ldc, Cpart, M, N, K, n_split, bn, mb, mt, nt, epilogue, dtype, stream);
+                                int32_t ring, int32_t epilogue, int32_t dtype, void* stream) {
+    return gemm_skinny(A, lda, W, ldw, false, C, ldc, Cpart, M, N, K, n_split, bn, mb, mt, nt, ring, epilogue, dtype, stream);
 }
 
 // The same GEMM on a weight stored K-tile-major: Wkt[K/64][N][64] (lade_weight_to_ktile).  Same arithmetic in the same order, so the
 // results are bit-identical to lade_gemm_skinny on the row-major weight; only the addresses the weight DMA reads differ.
 extern "C" int lade_gemm_skinny_kt(const void* A, int64_t lda, const void* Wkt, void* C, int64_t ldc, float* Cpart,
                                    int32_t M, int32_t N, int32_t K, int32_t n_split, int32_t bn, int32_t mb, int32_t mt, int32_t nt,
-                                   int32_t epilogue, int32_t dtype, void* stream) {
-    return gemm_skinny(A, lda, Wkt, 8, true, C, ldc, Cpart, M, N, K, n_split, bn, mb, mt, nt, epilogue, dtype, stream);
+                                   int32_t ring, int32_t epilogue, int32_t dtype, void* stream) {
+    return gemm_skinny(A, lda, Wkt, 8, true, C, ldc, Cpart, M, N, K, n_split, bn, mb, mt, nt, ring, epilogue, dtype, stream);
 }
 
 // Wkt[kt][n][0..63] = W[n][64 kt .. 64 kt + 63]: one 16-byte chunk per thread, a wave writes 1 KiB contiguous

@@ -10,16 +10,23 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// LDS ring depth: NSTG - 1 tiles stay in flight while one is multiplied.  3 by default; -DLADE_G_NSTAGE_MAX=n (experiments) lets every
-// shape take up to n stages, as many as fit the 160 KB of LDS.
-#ifndef LADE_G_NSTAGE_MAX
-#define LADE_G_NSTAGE_MAX 3
+// LDS ring depth: n_stage - 1 tiles stay in flight while one is multiplied.  It is a LAUNCH parameter (GemmK::n_stage, 2..G_NSTAGE_CAP):
+// a deeper ring keeps more bytes in flight per work-group but costs LDS, i.e. co-resident work-groups - which of the two a projection
+// needs depends on its split count, so the autotune picks the depth per (projection, row class).  Default (n_stage = 0 at the C ABI):
+// 4 stages where they fit, else as many as fit (round 4, same box in alternation: 3 -> 4 stages took the 7B step from 3.91 / 3.86 to
+// 3.78 / 3.77 ms; round 3 had measured -1.4 % on the isolated projections).
+#ifndef LADE_G_NSTAGE_DEFAULT
+#define LADE_G_NSTAGE_DEFAULT 4
 #endif
+constexpr int G_NSTAGE_CAP = 8;
+constexpr int G_LDS_MAX = 160 * 1024;
 constexpr int g_stages(int bn, int bm) {
-    const int fit = (160 * 1024) / ((bn + bm) * 128);
-    return fit < LADE_G_NSTAGE_MAX ? (fit < 3 ? 3 : fit) : LADE_G_NSTAGE_MAX;
+    const int fit = G_LDS_MAX / ((bn + bm) * 128);
+    // the compute-shaped 256 x 256 tile (64 KB per stage) runs as a double buffer; every other shape holds >= 3 stages
+    return fit < LADE_G_NSTAGE_DEFAULT ? (fit < 2 ? 2 : fit) : LADE_G_NSTAGE_DEFAULT;
 }
-// counted wait: at most `younger` whole tiles (of PIECES pieces per wave) may stay in flight
+// counted wait: at most `younger` whole tiles (of PIECES pieces per wave) may stay in flight (vmcnt holds 6 bits: beyond 63 pieces the
+// wait is stricter than needed, never weaker)
 template <int PIECES, int MAXY>
 __device__ __forceinline__ void g_wait_younger(int younger) {
     if constexpr (MAXY <= 0) {
@@ -70,7 +77,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
     constexpr int W_PIECES = W_BYTES / 1024, A_PIECES = A_BYTES / 1024;      // 1-KiB DMA pieces per tile
     constexpr int TOTAL_PIECES = W_PIECES + A_PIECES;
     constexpr int PIECES = (TOTAL_PIECES + NW - 1) / NW;                     // per wave and stage (the tail repeats the last piece)
-    constexpr int G_NSTAGE = g_stages(BN, BM);
+    const int NS = g.n_stage;                                                // ring depth of this launch (host-validated against the LDS)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -129,8 +136,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
                                                  (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     };
-#pragma unroll
-    for (int s = 0; s < G_NSTAGE; ++s)
+    for (int s = 0; s < NS; ++s)
         if (s < nt) issue(s, s);
 
     f32x16 acc[MT][NT];
@@ -141,10 +147,10 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][i][e] = 0.f;
 
+    int stage = 0;
     for (int i = 0; i < nt; ++i) {
-        const int stage = i % G_NSTAGE;
-        const int younger = min(nt, i + G_NSTAGE) - (i + 1);        // tiles requested after tile i that may stay in flight
-        g_wait_younger<PIECES, G_NSTAGE - 1>(younger);
+        const int younger = min(nt, i + NS) - (i + 1);        // tiles requested after tile i that may stay in flight
+        g_wait_younger<PIECES, G_NSTAGE_CAP - 1>(younger);
         g_barrier();
         const unsigned char* ws = smem + stage * STAGE;
         const unsigned char* as = ws + W_BYTES;
@@ -161,11 +167,12 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[a][j] = GMfma<T>::run(wf[j], af[a], acc[a][j]);
         }
-        if (i + G_NSTAGE < nt) {
+        if (i + NS < nt) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             g_barrier();
-            issue(i + G_NSTAGE, stage);
+            issue(i + NS, stage);
         }
+        stage = stage + 1 == NS ? 0 : stage + 1;
     }
 
     // ---- epilogue: C^T tile (lane = activation row ql of block mb, 16 weight rows per MFMA tile) -> row-major C ----
@@ -227,7 +234,8 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
                 *reinterpret_cast<u32x4*>(g.C + (size_t)(m0 + row) * g.ldc + n0 + c * 8) = *reinterpret_cast<const u32x4*>(stg + row * RS + c * 16);
         }
     } else if (g.dbg & 32) {
-        // experiment (LADE_GEMM_DBG=32): fp32 partials straight from the accumulators - lane (m = ql, hi) of tile (a, j) holds the four
+        // fp32 partials straight from the accumulators: shapes whose fp32 tile does not fit the LDS (the 256 x 256 tile: the launcher sets
+        // the bit) and the experiment LADE_GEMM_DBG=32 - lane (m = ql, hi) of tile (a, j) holds the four
         // consecutive weight rows n = 8*g4 + 4*hi .. +3 of activation row m, one 16-byte store each, no LDS staging and no barrier in
         // the tail.  Measured the same or slower than the staged whole-row stores below (7B, 60 rows: 92.9 vs 90.4-92.2 us per layer;
         // gate/up 40.2 vs 37.5-39.2): what the partial stores cost (16 us per layer, tools/gemm_flags.py with LADE_GEMM_DBG=1) is
@@ -252,7 +260,6 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
         constexpr int RSF = BN * 4 + 16;
         float* outp = g.Cpart + (size_t)split * g.M * g.N;
         unsigned char* stg = smem;
-        static_assert((size_t)BM * RSF <= (size_t)G_NSTAGE * STAGE, "fp32 staging must fit in the ring");
         if (computes)
 #pragma unroll
         for (int a = 0; a < MT; ++a)
@@ -285,14 +292,22 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
 
 // sums the n_split fp32 partials in split order and writes the model dtype:  C[m][n] = sum_s part[s][m][n]
 template <typename T, int MW, int MT, int NG, int NT>
-static int launch_gemm(const GemmK& g, hipStream_t st) {
+static int launch_gemm(const GemmK& g0, hipStream_t st) {
     constexpr int BN = 32 * NT * NG, BM = 32 * MW * MT;
-    constexpr int G_NSTAGE = g_stages(BN, BM);
-    constexpr size_t lds = (size_t)G_NSTAGE * (BN + BM) * 128;
-    static_assert(lds <= 160 * 1024, "LDS ring too large");
+    constexpr size_t STAGE = (size_t)(BN + BM) * 128;
+    GemmK g = g0;
+    if (g.n_stage == 0) g.n_stage = g_stages(BN, BM);
+    LADE_REQUIRE(g.n_stage >= 2 && g.n_stage <= G_NSTAGE_CAP && g.n_stage * STAGE <= (size_t)G_LDS_MAX, LADE_E_ARG,
+                 "lade_gemm_skinny: a ring of %d stages of %d + %d rows does not fit the %d KB of LDS", g.n_stage, BN, BM, G_LDS_MAX / 1024);
+    // the epilogue stages the [BM][BN] tile through the LDS (model dtype without split-K, fp32 partials with it); an fp32 tile larger
+    // than the LDS (the 256 x 256 shape) is stored straight from the accumulators instead
+    size_t stg = g.n_split == 1 ? (g.epi == 1 ? 0 : (size_t)BM * (BN * 2 + 16)) : (size_t)BM * (BN * 4 + 16);
+    if (g.n_split > 1 && stg > (size_t)G_LDS_MAX) { g.dbg |= 32; stg = 0; }
+    const size_t ring = g.n_stage * STAGE, lds = ring > stg ? ring : stg;
+    static_assert((size_t)BM * (BN * 2 + 16) <= (size_t)G_LDS_MAX, "model-dtype staging must fit the LDS");
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<T, MW, MT, NG, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<T, MW, MT, NG, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_MAX);
         attr = true;
     }
     dim3 grid(cdiv(g.N, BN), g.n_split, cdiv(g.M, BM));
@@ -315,7 +330,10 @@ static int launch_gemm(const GemmK& g, hipStream_t st) {
     /* 224-row weight blocks (N = 57344 = 256 x 224: Llama-2-70B gate/up on 256 CUs in one wave of work-groups) */        \
                    SHAPE(TT,1,1,7,1) SHAPE(TT,1,2,7,1) SHAPE(TT,1,3,7,1) SHAPE(TT,1,4,7,1)                                      \
     /* 192 rows */ SHAPE(TT,2,3,2,1) SHAPE(TT,2,3,4,1) SHAPE(TT,2,3,2,2) SHAPE(TT,3,2,2,1) SHAPE(TT,3,2,2,2)                                     \
-    /* 256 rows */ SHAPE(TT,2,4,2,1) SHAPE(TT,2,4,4,1) SHAPE(TT,2,4,2,2) SHAPE(TT,4,2,2,1) SHAPE(TT,4,2,2,2)
+    /* 256 rows */ SHAPE(TT,2,4,2,1) SHAPE(TT,2,4,4,1) SHAPE(TT,2,4,2,2) SHAPE(TT,4,2,2,1) SHAPE(TT,4,2,2,2)                                     \
+    /* 256 x 256 compute-shaped tile (steps and prefill chunks wider than 256 rows run as several row blocks): 4 x 2 / 2 x 4 MFMA tiles  \
+       per wave, 0.75 LDS fragment reads per MFMA, double-buffered 64 KB stages */                                        \
+                   SHAPE(TT,2,4,4,2) SHAPE(TT,4,2,2,4)
 
 // -1: no kernel for this wave grid
 template <typename T>

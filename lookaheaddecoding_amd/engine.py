@@ -109,11 +109,16 @@ class StepEngine:
         self.generation = 0                  # bumped whenever buffers are re-allocated (captured graphs become stale)
         dev, dt = self.device, dtype
 
-        def W(k):
+        self._aliased = set()               # (layer, projection) whose row-major weight is the CALLER's storage (HF drop-in: wo / wd)
+
+        def W(k, tag=None):
             # consume_weights: the entry is removed from the caller's dict as soon as it has been fused into the engine's
             # own layout, so a 140 GB model (Llama-2-70B in bf16) is never held twice
             src = weights.pop(k) if consume_weights else weights[k]
-            return src.to(device=dev, dtype=dt)
+            out = src.to(device=dev, dtype=dt)
+            if tag is not None and not consume_weights and out.is_contiguous() and out.data_ptr() == src.data_ptr():
+                self._aliased.add(tag)      # `.to()` was a no-op: releasing the engine's reference would free nothing
+            return out
 
         # tied embeddings: same storage (HF hands out a fresh tensor wrapper per `.weight.data`, so identity of the python objects
         # says nothing)
@@ -130,9 +135,9 @@ class StepEngine:
             self.layers.append(dict(
                 ln1=W(p + "ln1").contiguous(), ln2=W(p + "ln2").contiguous(),
                 wqkv=torch.cat([W(p + "wq"), W(p + "wk"), W(p + "wv")], dim=0).contiguous(),
-                wo=W(p + "wo").contiguous(),
+                wo=W(p + "wo", (i, "wo")).contiguous(),
                 wgu=self._fuse_gate_up(W(p + "wg"), W(p + "wu")),
-                wd=W(p + "wd").contiguous()))
+                wd=W(p + "wd", (i, "wd")).contiguous()))
         # hand-written weight-streaming GEMM (split-K partials consumed by the fused glue kernels) for steps of
         # <= 256 tokens; every (N, K, row class) is timed against the library GEMM once and the faster one is kept
         self.custom_gemm = dt != torch.float32 and os.environ.get("LADE_GEMM", "1") != "0" and self.d % 16 == 0 and self.hidden % 64 == 0 and self.inter % 64 == 0
@@ -164,37 +169,70 @@ class StepEngine:
     def _build_ktile_copies(self) -> None:
         """K-TILE-MAJOR projection weights ([K/64][N][64], `lade_weight_to_ktile`) for the skinny GEMM: the 128-byte segments of all rows of
         one K tile are contiguous, so a work-group's tile is one contiguous read and the work-groups of a split sweep memory linearly
-        (7B projections at 60 rows: 88.8 -> 79.2 us per layer, 70B: 296.5 -> 261.4, bit-identical results).
-          * "dual" (it fits: 13 GB more at 7B, 26 GB at 13B of the 288 GB): a second copy; the row-major weights stay for the library
-            GEMM (prefill chunks, steps wider than 256 rows) - HBM spent to buy bandwidth;
-          * "only" (a model that cannot be held twice: Llama-2-70B in bf16): the weights are converted one by one and the row-major
-            originals released; the library GEMM of a wide step gets its row-major operand from `lade_weight_from_ktile` into one
-            scratch per projection (prefill pays one extra pass over the weights per chunk, decode steps gain ~12 %).
-        LADE_W_KTILE = 0 | 1 (dual) | only overrides the decision."""
+        (7B projections at 60 rows: 88.8 -> 79.2 us per layer, 70B: 296.5 -> 261.4, bit-identical results).  The library
+        GEMM (prefill chunks where it is the faster kernel) reads row-major weights, so the HBM decides what is held:
+          * "dual" (everything fits twice: 13 GB more at 7B, 26 GB at 13B of the 288 GB): a second copy of every projection;
+          * otherwise (Llama-2-70B in bf16) every projection the engine OWNS is converted layer by layer and its row-major original is
+            kept only while the HBM budget lasts (free memory - KV cache - workspaces - KTILE_RESERVE): the first layers stay in both
+            layouts, the rest K-tile-major only - their library GEMMs get a row-major operand from `lade_weight_from_ktile` into one
+            scratch per projection.  (Round 3 released every original: 70B prefill paid 320 rebuilds, 7.1 k -> 6.1 k tokens/s, while
+            ~120 GB of HBM sat unused.)
+          * a projection whose row-major weight is the CALLER's storage (HF drop-in without consume_weights: o / down are the module's
+            own tensors, `.to()` is a no-op) cannot be released by the engine: when the copies do not all fit it keeps the row-major
+            layout for every kernel and gets NO K-tile copy (a copy would be pure extra memory).
+        LADE_W_KTILE = 0 | 1 (dual) | only (release every owned original) overrides the decision; LADE_KTILE_BUDGET_MB the budget."""
         want = os.environ.get("LADE_W_KTILE", "auto")
+        self.kt_names: tuple = ()            # projections streamed K-tile-major by the decode GEMMs
+        self.rows_kept, self.rows_total = 0, 0
         if not self.custom_gemm or want == "0":
             return
-        extra = sum(lw[n].numel() * lw[n].element_size() for lw in self.layers for n in self.LAYER_GEMMS)
-        only = want == "only"
-        if want == "auto":
-            free, _total = torch.cuda.mem_get_info(self.device)
-            # what is allocated after this: the KV cache and the step workspaces of the configured sizes, + a fixed reserve for the
-            # library's workspaces, the n-gram pool and growth
-            esz = self.layers[0]["wo"].element_size()
-            later = 2 * self.L * self.Hkv * self.S_max * self.d * esz + 16 * 128 * max((self.H + 2 * self.Hkv) * self.d, 2 * self.inter) * 4
-            only = free < extra + later + self.KTILE_RESERVE
+        nbytes = lambda t: t.numel() * t.element_size()
+        extra = sum(nbytes(lw[n]) for lw in self.layers for n in self.LAYER_GEMMS)
+        torch.cuda.empty_cache()             # blocks sitting free in torch's caching allocator are memory the copies can use
+        free, _total = torch.cuda.mem_get_info(self.device)
+        # what is allocated after this: the KV cache and the step workspaces of the configured sizes, + a fixed reserve for the
+        # library's workspaces, the n-gram pool and growth
+        esz = self.layers[0]["wo"].element_size()
+        later = 2 * self.L * self.Hkv * self.S_max * self.d * esz + 16 * 128 * max((self.H + 2 * self.Hkv) * self.d, 2 * self.inter) * 4
+        budget = free - later - self.KTILE_RESERVE
+        if os.environ.get("LADE_KTILE_BUDGET_MB"):
+            budget = int(float(os.environ["LADE_KTILE_BUDGET_MB"]) * (1 << 20))
+        dual = want == "1" or (want == "auto" and extra <= budget)
+        aliased_names = {n for (_li, n) in self._aliased}
+        names = self.LAYER_GEMMS if dual else tuple(n for n in self.LAYER_GEMMS if n not in aliased_names)
         with torch.cuda.device(self.device):            # the C ABI launches on the current device's current stream
-            if only:
+            if not dual and names:
                 # one scratch per projection for the library GEMM's row-major operand, allocated before the conversion frees anything
-                self._row_scratch = {n: torch.empty_like(self.layers[0][n]) for n in self.LAYER_GEMMS}
+                self._row_scratch = {n: torch.empty_like(self.layers[0][n]) for n in names}
+                budget -= sum(nbytes(t) for t in self._row_scratch.values())
             for lw in self.layers:
-                for n in self.LAYER_GEMMS:
+                for n in names:
                     lw[n + "_kt"] = ops.to_ktile(lw[n])
-                    if only:
+                    self.rows_total += 1
+                    budget -= nbytes(lw[n])
+                    if not dual and (want == "only" or budget < 0):
+                        budget += nbytes(lw[n])
                         del lw[n]                       # the allocator hands the block to the next conversion
-        self.ktile, self.ktile_only = True, only
-        self.ktile_bytes = (0 if only else extra) + self._lm_head.numel() * self._lm_head.element_size()
+                    else:
+                        self.rows_kept += 1
+        self.kt_names = tuple(names)
+        self.ktile = bool(names)
+        self.ktile_only = bool(names) and self.rows_kept == 0          # no row-major original of a converted projection is left
+        self.ktile_bytes = sum(nbytes(lw[n + "_kt"]) for lw in self.layers for n in names if n in lw) + nbytes(self._lm_head)
         self.lm_head = self._lm_head                 # builds its copy (the output projection is small: always held in both layouts)
+
+    def refresh_ktile(self) -> None:
+        """Re-derives the K-tile-major copies from the row-major weights after an IN-PLACE update of the latter (weight reload, adapter
+        merge, an edit of tied embeddings): prefill and wide steps read the row-major tensors live - for o / down on the HF path those are
+        the module's own storage - while decode steps stream the copies made at construction.  Projections whose row-major original was
+        released have no second layout to go stale (edit `layers[i][name + "_kt"]` through `ops.to_ktile`).  Captured hipGraphs read the
+        same buffers, so they stay valid."""
+        with torch.cuda.device(self.device):
+            for lw in self.layers:
+                for n in self.kt_names:
+                    if n in lw:
+                        ops.to_ktile(lw[n], out=lw[n + "_kt"])
+            self.lm_head = self._lm_head
 
     @property
     def lm_head(self) -> torch.Tensor:
@@ -221,7 +259,8 @@ class StepEngine:
 
     def _w(self, lw: dict, name: str) -> torch.Tensor:
         """the weight the skinny GEMM streams: the K-tile-major copy when the engine holds one"""
-        return lw[name + "_kt"] if self.ktile else lw[name]
+        kt = lw.get(name + "_kt")
+        return kt if kt is not None else lw[name]
 
     def _row(self, lw: dict, name: str) -> torch.Tensor:
         """the row-major weight a library GEMM takes; K-tile-only engines rebuild it into the projection's scratch (same stream: ordered
@@ -309,7 +348,7 @@ class StepEngine:
 
     # ---- GEMM selection ---------------------------------------------------------------------------
     def _tune(self, name: str, M: int):
-        """(mb, bn, n_split, mt, nt) of the split-K GEMM for projection `name` at a step of M rows, or None when the library
+        """(mb, bn, n_split, mt, nt, ring) of the split-K GEMM for projection `name` at a step of M rows, or None when the library
         GEMM is faster.  Timed once per (projection, row class) on this GPU, rotating through the layers' weights so the
         stream comes from HBM rather than from the Infinity Cache."""
         mclass = next(c for c in self.ROW_CLASSES if M <= c)
@@ -319,7 +358,10 @@ class StepEngine:
         if name == "lm_head":
             ws = ([self._lm_head], [self._lm_kt if self._lm_kt is not None else self._lm_head])
         else:         # (row-major: library GEMM - none when the weights are held K-tile-major only, what the skinny GEMM streams)
-            ws = (None if self.ktile_only else [lw[name] for lw in self.layers], [self._w(lw, name) for lw in self.layers])
+            # the library is a candidate for a decode-width step only when EVERY layer still holds the row-major weight (a layer whose
+            # original was released would pay a rebuild per call)
+            rows = [lw[name] for lw in self.layers if name in lw]
+            ws = (rows if len(rows) == self.L else None, [self._w(lw, name) for lw in self.layers])
         N, K = self._nk(ws[1][0])
         # one decision per (shape, row class, dtype) and process: engines of the same model (lookahead-parallel ranks run as
         # threads, a decoder rebuilt on the same weights) must pick the same kernel, or their 16-bit results round differently
@@ -391,10 +433,10 @@ class StepEngine:
             tail = lambda out_bytes: out_bytes / rate
         # + the consumer's extra read; K-tile-only weights: the library would need its row-major operand rebuilt per call - not a candidate
         t_lib = float("inf") if ws_lib is None else time_it(lambda i: torch.matmul(a, ws_lib[i % len(ws_lib)].t(), out=out)) + 0.003 + tail(Mrows * N * 2)
-        timed = []                        # (ms incl. the consumer tail, (mb, bn, S, mt, nt))
+        timed = []                        # (ms incl. the consumer tail, (mb, bn, S, mt, nt, ring))
         for (mb, bn, S, mt, nt) in cands:
             t = time_it(lambda i: ops.gemm_parts(a, ws[i % len(ws)], self.ws_part, S, bn, mb, mt, nt)) + tail(S * Mrows * N * 4)
-            timed.append((t, (mb, bn, S, mt, nt)))
+            timed.append((t, (mb, bn, S, mt, nt, 0)))
         act = None
         if name == "wgu" and self.gu_layout == 1:
             # no split-K: BN weight rows x the whole K per work-group, SwiGLU in the epilogue, output in the model dtype.  Needs
@@ -409,7 +451,24 @@ class StepEngine:
                         t = time_it(lambda i: ops.gemm_swiglu(a, ws[i % len(ws)], act, bn, mbs, mt, 1))
                     except cabi.LadeHipError:
                         continue                      # wave grid not built for this row class
-                    timed.append((t, (mbs, bn, 1, mt, 1)))
+                    timed.append((t, (mbs, bn, 1, mt, 1, 0)))
+        # second pass: the LDS ring depth of the best few.  More stages = more bytes in flight per work-group, fewer work-groups per CU;
+        # which of the two a projection needs depends on its split count (an unsplit gate/up GEMM is one work-group per CU whatever the
+        # ring costs, a 512-work-group split-K launch needs two per CU), so the depth is a per-kernel decision like the shape itself
+        if os.environ.get("LADE_TUNE_RING", "1") != "0":
+            for t0, (mb, bn, S, mt, nt, _r) in sorted(timed)[:3]:
+                stage_bytes = (bn + 32 * mb) * 128
+                for ring in (3, 5, 6, 8):
+                    if ring * stage_bytes > 160 * 1024 or ring == min(4, 160 * 1024 // stage_bytes):
+                        continue
+                    try:
+                        if S == 1:
+                            t = time_it(lambda i: ops.gemm_swiglu(a, ws[i % len(ws)], act, bn, mb, mt, nt, ring))
+                        else:
+                            t = time_it(lambda i: ops.gemm_parts(a, ws[i % len(ws)], self.ws_part, S, bn, mb, mt, nt, ring)) + tail(S * Mrows * N * 4)
+                    except cabi.LadeHipError:
+                        continue
+                    timed.append((t, (mb, bn, S, mt, nt, ring)))
         best, t_best = None, t_lib
         if timed and min(timed)[0] < t_lib:
             t_best, best = min(timed)
@@ -453,7 +512,18 @@ class StepEngine:
                         t = time_it(lambda: ops.gemm_skinny(a, ws[0], out=out, n_split=1, bn=bn, mb=mbs, mt=mt, nt=nt))
                     except cabi.LadeHipError:
                         continue                      # wave grid not built for this row class
-                    timed.append((t, (mbs, bn, 1, mt, nt)))
+                    timed.append((t, (mbs, bn, 1, mt, nt, 0)))
+        if os.environ.get("LADE_TUNE_RING", "1") != "0":
+            for t0, (mb, bn, S, mt, nt, _r) in sorted(timed)[:2]:
+                stage_bytes = (bn + 32 * mb) * 128
+                for ring in (3, 5, 6, 8):
+                    if ring * stage_bytes > 160 * 1024 or ring == min(4, 160 * 1024 // stage_bytes):
+                        continue
+                    try:
+                        t = time_it(lambda: ops.gemm_skinny(a, ws[0], out=out, n_split=1, bn=bn, mb=mb, mt=mt, nt=nt, ring=ring))
+                    except cabi.LadeHipError:
+                        continue
+                    timed.append((t, (mb, bn, 1, mt, nt, ring)))
         best, t_best = None, t_lib
         if timed and min(timed)[0] < t_lib:
             t_best, best = min(timed)
@@ -478,7 +548,7 @@ class StepEngine:
     def adopt_gemm_cfg(self, table: dict) -> None:
         for k, v in table.items():
             n, m = k.split(":")
-            self.gemm_cfg[(n, int(m))] = None if v is None else tuple(v)
+            self.gemm_cfg[(n, int(m))] = None if v is None else (tuple(v) + (0,))[:6]       # (a 5-tuple of an older table: default ring)
 
     # ---- one forward -----------------------------------------------------------------------------
     @_on_device
@@ -511,7 +581,7 @@ class StepEngine:
             else:
                 ops.add_rmsnorm(x, r, lw["ln1"], self.eps, out=h)
             if cfg_qkv:
-                ops.gemm_parts(h, self._w(lw, "wqkv"), part, cfg_qkv[2], cfg_qkv[1], cfg_qkv[0], cfg_qkv[3], cfg_qkv[4])
+                ops.gemm_parts(h, self._w(lw, "wqkv"), part, cfg_qkv[2], cfg_qkv[1], cfg_qkv[0], cfg_qkv[3], cfg_qkv[4], cfg_qkv[5])
                 qb = self.ws_q[:T]
                 ops.rope_kv_append_parts(part, cfg_qkv[2], qb, pos, self.cos, self.sin, self.k_cache(li), self.vt_cache(li), T, P, H=H, Hkv=Hkv, d=d, dyn_P=dyn_P)
                 q_in = qb
@@ -536,21 +606,21 @@ class StepEngine:
                 e1.record()
                 ev.append((e0, e1, mask.T, n_splits))
             if cfg_o:
-                ops.gemm_parts(o, self._w(lw, "wo"), part, cfg_o[2], cfg_o[1], cfg_o[0], cfg_o[3], cfg_o[4])
+                ops.gemm_parts(o, self._w(lw, "wo"), part, cfg_o[2], cfg_o[1], cfg_o[0], cfg_o[3], cfg_o[4], cfg_o[5])
                 ops.add_rmsnorm_parts(x, part, cfg_o[2], lw["ln2"], self.eps, out=h)      # x += attn; h = norm(x)
             else:
                 torch.matmul(o, self._row(lw, "wo").t(), out=r)
                 ops.add_rmsnorm(x, r, lw["ln2"], self.eps, out=h)
             if cfg_gu and cfg_gu[2] == 1:                 # gate/up GEMM + SwiGLU in one launch
-                ops.gemm_swiglu(h, self._w(lw, "wgu"), a, cfg_gu[1], cfg_gu[0], cfg_gu[3], cfg_gu[4])
+                ops.gemm_swiglu(h, self._w(lw, "wgu"), a, cfg_gu[1], cfg_gu[0], cfg_gu[3], cfg_gu[4], cfg_gu[5])
             elif cfg_gu:
-                ops.gemm_parts(h, self._w(lw, "wgu"), part, cfg_gu[2], cfg_gu[1], cfg_gu[0], cfg_gu[3], cfg_gu[4])
+                ops.gemm_parts(h, self._w(lw, "wgu"), part, cfg_gu[2], cfg_gu[1], cfg_gu[0], cfg_gu[3], cfg_gu[4], cfg_gu[5])
                 ops.silu_mul_parts(part, cfg_gu[2], T, self.inter, out=a, layout=self.gu_layout)
             else:
                 torch.matmul(h, self._row(lw, "wgu").t(), out=gu)
                 ops.silu_mul(gu, out=a, layout=self.gu_layout)
             if cfg_d:
-                ops.gemm_parts(a, self._w(lw, "wd"), part, cfg_d[2], cfg_d[1], cfg_d[0], cfg_d[3], cfg_d[4])
+                ops.gemm_parts(a, self._w(lw, "wd"), part, cfg_d[2], cfg_d[1], cfg_d[0], cfg_d[3], cfg_d[4], cfg_d[5])
                 r_parts = cfg_d[2]
             else:
                 torch.matmul(a, self._row(lw, "wd").t(), out=r)
@@ -566,7 +636,7 @@ class StepEngine:
         if cfg_lm:
             logits = torch.empty(n_sel, self.V, dtype=self.dtype, device=self.device)
             return ops.gemm_skinny(hn, self._lm_kt if self._lm_kt is not None else self._lm_head, out=logits, n_split=1,
-                                   bn=cfg_lm[1], mb=cfg_lm[0], mt=cfg_lm[3], nt=cfg_lm[4])
+                                   bn=cfg_lm[1], mb=cfg_lm[0], mt=cfg_lm[3], nt=cfg_lm[4], ring=cfg_lm[5])
         return torch.matmul(hn, self._lm_head.t())
 
     # ---- prefill: plain causal rows over the growing cache ---------------------------------------------

@@ -265,13 +265,15 @@ def softmax_gather(logits: torch.Tensor, rows: int, skip: int, guess: torch.Tens
          g_cap, ptr(scal), ptr(stats))
 
 
-def to_ktile(w: torch.Tensor) -> torch.Tensor:
+def to_ktile(w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Row-major weight [N, K] -> the K-tile-major copy [K/64, N, 64] the skinny GEMM streams fastest (`lade_weight_to_ktile`): the
     128-byte segments of all N rows of one 64-deep K tile are contiguous.  The GEMM wrappers below tell the two layouts apart by the
     number of dimensions."""
     N, K = w.shape
     assert w.stride(1) == 1 and K % 64 == 0
-    out = torch.empty(K // 64, N, 64, dtype=w.dtype, device=w.device)
+    if out is None:
+        out = torch.empty(K // 64, N, 64, dtype=w.dtype, device=w.device)
+    assert out.shape == (K // 64, N, 64) and out.is_contiguous() and out.dtype == w.dtype
     call("lade_weight_to_ktile", ptr(w), w.stride(0), ptr(out), N, K, dtype_code(w))
     return out
 
@@ -287,15 +289,15 @@ def from_ktile(wkt: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.T
     return out
 
 
-def _gemm(a: torch.Tensor, w: torch.Tensor, c, ldc: int, part, n_split: int, bn: int, mb: int, mt: int, nt: int, epilogue: int) -> None:
+def _gemm(a: torch.Tensor, w: torch.Tensor, c, ldc: int, part, n_split: int, bn: int, mb: int, mt: int, nt: int, epilogue: int, ring: int = 0) -> None:
     M, K = a.shape
     assert a.stride(1) == 1
     if w.dim() == 3:                          # K-tile-major [K/64, N, 64]
         assert w.is_contiguous() and w.shape[0] * 64 == K and w.shape[2] == 64
-        call("lade_gemm_skinny_kt", ptr(a), a.stride(0), ptr(w), c, ldc, part, M, w.shape[1], K, n_split, bn, mb, mt, nt, epilogue, dtype_code(a))
+        call("lade_gemm_skinny_kt", ptr(a), a.stride(0), ptr(w), c, ldc, part, M, w.shape[1], K, n_split, bn, mb, mt, nt, ring, epilogue, dtype_code(a))
     else:
         assert w.shape[1] == K and w.stride(1) == 1
-        call("lade_gemm_skinny", ptr(a), a.stride(0), ptr(w), w.stride(0), c, ldc, part, M, w.shape[0], K, n_split, bn, mb, mt, nt, epilogue, dtype_code(a))
+        call("lade_gemm_skinny", ptr(a), a.stride(0), ptr(w), w.stride(0), c, ldc, part, M, w.shape[0], K, n_split, bn, mb, mt, nt, ring, epilogue, dtype_code(a))
 
 
 def weight_rows(w: torch.Tensor) -> int:
@@ -304,34 +306,35 @@ def weight_rows(w: torch.Tensor) -> int:
 
 
 def gemm_skinny(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, n_split: int = 1, bn: int = 128,
-                part: Optional[torch.Tensor] = None, mb: int = 0, mt: int = 0, nt: int = 0) -> torch.Tensor:
-    """out[M,N] = a[M,K] @ w[N,K]^T on the hand-written weight-streaming kernel (bf16 / f16); w row-major or K-tile-major (to_ktile)."""
+                part: Optional[torch.Tensor] = None, mb: int = 0, mt: int = 0, nt: int = 0, ring: int = 0) -> torch.Tensor:
+    """out[M,N] = a[M,K] @ w[N,K]^T on the hand-written weight-streaming kernel (bf16 / f16); w row-major or K-tile-major (to_ktile).
+    ring: stages of the LDS ring (0 = the shape's default)."""
     M, N = a.shape[0], weight_rows(w)
     if out is None:
         out = torch.empty(M, N, dtype=a.dtype, device=a.device)
     if n_split > 1 and part is None:
         part = torch.empty(n_split, M, N, dtype=torch.float32, device=a.device)
-    _gemm(a, w, ptr(out), out.stride(0), ptr(part), n_split, bn, mb, mt, nt, 0)
+    _gemm(a, w, ptr(out), out.stride(0), ptr(part), n_split, bn, mb, mt, nt, 0, ring)
     if n_split > 1:
         call("lade_splitk_reduce", ptr(part), ptr(out), out.stride(0), M, N, n_split, dtype_code(a))
     return out
 
 
-def gemm_swiglu(a: torch.Tensor, w_gu: torch.Tensor, out: torch.Tensor, bn: int, mb: int, mt: int = 0, nt: int = 0) -> torch.Tensor:
+def gemm_swiglu(a: torch.Tensor, w_gu: torch.Tensor, out: torch.Tensor, bn: int, mb: int, mt: int = 0, nt: int = 0, ring: int = 0) -> torch.Tensor:
     """out[M, inter] = silu(a @ gate^T) * (a @ up^T) in ONE launch: w_gu is the 16-row interleaved fused weight (interleave_gate_up),
     row-major or K-tile-major; no split-K, no fp32 partials, no SwiGLU kernel."""
     assert out.shape == (a.shape[0], weight_rows(w_gu) // 2) and out.stride(1) == 1
-    _gemm(a, w_gu, ptr(out), out.stride(0), None, 1, bn, mb, mt, nt, 1)
+    _gemm(a, w_gu, ptr(out), out.stride(0), None, 1, bn, mb, mt, nt, 1, ring)
     return out
 
 
-def gemm_parts(a: torch.Tensor, w: torch.Tensor, part: torch.Tensor, n_split: int, bn: int, mb: int, mt: int = 0, nt: int = 0) -> None:
+def gemm_parts(a: torch.Tensor, w: torch.Tensor, part: torch.Tensor, n_split: int, bn: int, mb: int, mt: int = 0, nt: int = 0, ring: int = 0) -> None:
     """split-K GEMM that leaves its result as n_split fp32 partials in `part` ([n_split][M][N], contiguous) for a
     `*_parts` consumer kernel - no reduce pass."""
     M, N = a.shape[0], weight_rows(w)
     if n_split * M * N > part.numel():
         raise cabi.LadeHipError(f"split-K workspace too small: {n_split} x {M} x {N} fp32 partials > {part.numel()}")
-    _gemm(a, w, None, 0, ptr(part), n_split, bn, mb, mt, nt, 0)
+    _gemm(a, w, None, 0, ptr(part), n_split, bn, mb, mt, nt, 0, ring)
 
 
 def add_rmsnorm_parts(x: torch.Tensor, part: torch.Tensor, n_parts: int, w: torch.Tensor, eps: float, out: torch.Tensor) -> torch.Tensor:

@@ -145,7 +145,7 @@ class RcclComm:
 
 
 # ---- rank 0's GEMM autotune table as a fixed int32 block (so that it can travel through the step's own all-gather) ----
-_TUNE_FIELDS = 6           # present flag + (mb, bn, S, mt, nt)
+_TUNE_FIELDS = 7           # present flag + (mb, bn, S, mt, nt, ring)
 
 
 def encode_tune_table(table: dict, names: Sequence[str], classes: Sequence[int]) -> List[int]:
@@ -153,7 +153,7 @@ def encode_tune_table(table: dict, names: Sequence[str], classes: Sequence[int])
     for n in names:
         for m in classes:
             v = table.get(f"{n}:{m}")
-            out += [0] * _TUNE_FIELDS if v is None else [1] + [int(x) for x in v]
+            out += [0] * _TUNE_FIELDS if v is None else [1] + ([int(x) for x in v] + [0])[:_TUNE_FIELDS - 1]       # (5-tuples of older tables: default ring)
     return out
 
 

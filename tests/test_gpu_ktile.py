@@ -8,6 +8,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from lookaheaddecoding_amd import cabi
 from lookaheaddecoding_amd.weights import make_config, random_weights_numpy
 
 
@@ -185,3 +186,118 @@ def test_ktile_layout_decision_dual_when_it_fits_only_when_it_does_not(monkeypat
     assert not e.ktile and e.ktile_bytes == 0 and all(n in lw for lw in e.layers for n in e.LAYER_GEMMS)
     e = StepEngine(cfg, w, dtype=torch.float32, max_seq=256, max_T=64)              # fp32 has no skinny GEMM: nothing to copy
     assert not e.ktile
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_ring_depth_is_a_launch_parameter_and_never_changes_a_bit(dtype):
+    """the LDS ring depth (C ABI `ring`, chosen per projection by the engine's autotune) changes how many tiles are in flight, not the
+    arithmetic: every depth 2..8 that fits the LDS gives the bits of the default, for split-K partials, the direct output, the SwiGLU
+    epilogue and a K range shorter than the ring; a ring that does not fit is refused"""
+    from lookaheaddecoding_amd import ops
+    torch.manual_seed(3)
+    for (M, N, K, (bn, mb, mt, nt), S) in [(60, 1000, 1024, (96, 2, 1, 1), 2), (60, 512, 4096, (128, 2, 2, 0), 8), (120, 776, 512, (192, 4, 2, 0), 1),
+                                           (30, 264, 128, (64, 1, 1, 0), 1), (240, 520, 640, (128, 8, 4, 1), 2)]:
+        a = torch.randn(M, K, device="cuda").to(dtype)
+        wk = ops.to_ktile((torch.randn(N, K, device="cuda") * 0.05).to(dtype))
+        ref = ops.gemm_skinny(a, wk, n_split=S, bn=bn, mb=mb, mt=mt, nt=nt)
+        fits = [r for r in range(2, 9) if r * (bn + 32 * mb) * 128 <= 160 * 1024]
+        assert fits
+        for ring in fits:
+            assert torch.equal(ops.gemm_skinny(a, wk, n_split=S, bn=bn, mb=mb, mt=mt, nt=nt, ring=ring), ref), (M, N, K, S, ring)
+        for ring in set(range(2, 9)) - set(fits):
+            with pytest.raises(cabi.LadeHipError):
+                ops.gemm_skinny(a, wk, n_split=S, bn=bn, mb=mb, mt=mt, nt=nt, ring=ring)
+    with pytest.raises(cabi.LadeHipError):
+        ops.gemm_skinny(a, wk, n_split=1, bn=128, mb=8, mt=4, nt=1, ring=9)
+    # SwiGLU epilogue
+    inter, hid, M = 352, 256, 60
+    wg, wu = [(torch.randn(inter, hid, device="cuda") * 0.05).to(dtype) for _ in range(2)]
+    wf = ops.to_ktile(ops.interleave_gate_up(wg, wu))
+    a = torch.randn(M, hid, device="cuda").to(dtype)
+    o = [torch.empty(M, inter, dtype=dtype, device="cuda") for _ in range(3)]
+    ops.gemm_swiglu(a, wf, o[0], 96, 2, 1, 1)
+    ops.gemm_swiglu(a, wf, o[1], 96, 2, 1, 1, ring=3)
+    ops.gemm_swiglu(a, wf, o[2], 96, 2, 1, 1, ring=7)
+    assert torch.equal(o[0], o[1]) and torch.equal(o[0], o[2])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_wider_than_256_rows_runs_as_row_blocks_on_every_tile_shape(dtype):
+    """M > 256 (the reference's default W = 60, N = 8, G = 60 feeds 847 rows; prefill chunks 2304): several 256-row blocks per launch.
+    Every output element is one K-ordered MFMA accumulation whatever the tile shape, so the 128-row-wide tiles, the compute-shaped
+    256 x 256 tile (double-buffered) and the <= 256-row launches of the decode step all give the same bits; split-K partials of the
+    256 x 256 tile (stored straight from the accumulators) equal those of the staged shapes; and the result is the fp32 product"""
+    from lookaheaddecoding_amd import ops
+    torch.manual_seed(4)
+    for (M, N, K) in [(300, 520, 256), (512, 1024, 1024), (847, 776, 512), (2304, 264, 384)]:
+        a = torch.randn(M, K, device="cuda").to(dtype)
+        w = (torch.randn(N, K, device="cuda") * 0.05).to(dtype)
+        wk = ops.to_ktile(w)
+        base = torch.cat([ops.gemm_skinny(a[r0:r0 + 240], wk, n_split=1, bn=128, mb=8, mt=4, nt=1) for r0 in range(0, M, 240)])
+        for (bn, mt, nt) in [(128, 4, 1), (128, 2, 2), (64, 4, 1), (256, 4, 2), (256, 2, 4)]:
+            for W_ in (w, wk):
+                got = ops.gemm_skinny(a, W_, n_split=1, bn=bn, mb=8, mt=mt, nt=nt)
+                assert torch.equal(got, base), (M, N, K, bn, mt, nt, W_.dim())
+        ref = a.float() @ w.float().t()
+        assert torch.allclose(base.float(), ref, atol=0.02 * K ** 0.5 * 0.05 + 0.02, rtol=2e-2)
+        p0 = torch.full((2 * M * N,), float("nan"), dtype=torch.float32, device="cuda")
+        p1 = torch.full((2 * M * N,), float("nan"), dtype=torch.float32, device="cuda")
+        ops.gemm_parts(a, wk, p0, 2, 128, 8, 4, 1)
+        ops.gemm_parts(a, wk, p1, 2, 256, 8, 4, 2)
+        assert torch.isfinite(p0).all() and torch.equal(p0, p1), (M, N, K)
+
+
+def test_weight_memory_plan_keeps_row_major_originals_while_the_budget_lasts_and_skips_aliased_projections(monkeypatch):
+    """what `_build_ktile_copies` decides when a second copy of everything does not fit (Llama-2-70B): owned projections are converted
+    and their row-major originals kept for the first layers only (the budget), released for the rest - prefill then rebuilds the
+    operand for those layers alone; projections whose row-major weight is the CALLER's storage (HF drop-in: o / down) are neither
+    released nor copied.  The logits of a decode-width step and of a library prefill chunk are bit-identical to the all-row-major engine;
+    `refresh_ktile` carries an in-place edit of an aliased weight into the copy the decode steps stream."""
+    from lookaheaddecoding_amd import ops
+    from lookaheaddecoding_amd.engine import StepEngine
+    cfg = make_config("tiny-d128", max_pos=1024)
+    w_cpu = {k: torch.as_tensor(v) for k, v in random_weights_numpy(cfg, seed=8, std=0.05).items()}
+    w_gpu = {k: v.to("cuda", torch.bfloat16) for k, v in w_cpu.items()}            # an HF-like caller: the tensors already live on the GPU
+    nbytes = lambda t: t.numel() * t.element_size()
+    monkeypatch.setenv("LADE_W_KTILE", "0")
+    e0 = StepEngine(cfg, w_gpu, dtype=torch.bfloat16, max_seq=1024, max_T=512)
+    assert {n for (_l, n) in e0._aliased} == {"wo", "wd"} and len(e0._aliased) == 2 * cfg["layers"]
+    per_layer = sum(nbytes(e0.layers[0][n]) for n in ("wqkv", "wgu"))
+    scratch = per_layer
+    # budget: the scratch + ONE layer's originals (+ a margin far below a second layer's)
+    monkeypatch.setenv("LADE_W_KTILE", "auto")
+    monkeypatch.setenv("LADE_KTILE_BUDGET_MB", repr((scratch + per_layer + 4096) / (1 << 20)))
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_allocated()
+    e1 = StepEngine(cfg, w_gpu, dtype=torch.bfloat16, max_seq=1024, max_T=512)
+    assert e1.kt_names == ("wqkv", "wgu") and e1.ktile and not e1.ktile_only
+    assert all("wo_kt" not in lw and "wd_kt" not in lw and lw["wo"].data_ptr() == w_gpu[f"layers.{i}.wo"].data_ptr() for i, lw in enumerate(e1.layers))
+    assert [("wqkv" in lw, "wgu" in lw) for lw in e1.layers] == [(True, True)] + [(False, False)] * (cfg["layers"] - 1)
+    assert e1.rows_kept == 2 and e1.rows_total == 2 * cfg["layers"]
+    # an owned-everything engine under the same budget converts all four projections
+    e2 = StepEngine(cfg, w_cpu, dtype=torch.bfloat16, max_seq=1024, max_T=512)
+    assert e2.kt_names == e2.LAYER_GEMMS and not e2._aliased
+    monkeypatch.delenv("LADE_KTILE_BUDGET_MB")
+    table = e0.tune_all()
+    for e in (e1, e2):
+        e.adopt_gemm_cfg(table)
+    g = torch.Generator().manual_seed(9)
+    prompt = torch.randint(3, cfg["vocab"], (300,), generator=g).tolist()
+    P, T = len(prompt), 60
+    ids = torch.randint(3, cfg["vocab"], (T,), generator=g).to(torch.int32).cuda()
+    pos = (P + torch.arange(T)).to(torch.int32).cuda()
+    sel = torch.arange(T, dtype=torch.int32).cuda()
+    outs = []
+    for e in (e0, e1, e2):
+        lg_p, _ = e.prefill(prompt, rows=[P - 1])
+        outs.append((lg_p.clone(), e.forward(ids, pos, ops.StepMask(T=T, P=P, is_prefill=True), sel, T).clone()))
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
+    # in-place update of a weight the dual engine aliases / copies: refresh_ktile() re-derives the streamed copies
+    monkeypatch.setenv("LADE_W_KTILE", "1")
+    e3 = StepEngine(cfg, w_gpu, dtype=torch.bfloat16, max_seq=1024, max_T=512)
+    assert e3.kt_names == e3.LAYER_GEMMS and e3.rows_kept == e3.rows_total
+    w_gpu["layers.0.wo"].mul_(0.5)
+    assert not torch.equal(e3.layers[0]["wo_kt"], ops.to_ktile(e3.layers[0]["wo"]))
+    e3.refresh_ktile()
+    assert all(torch.equal(lw[n + "_kt"], ops.to_ktile(lw[n])) for lw in e3.layers for n in e3.LAYER_GEMMS)

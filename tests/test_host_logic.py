@@ -157,13 +157,13 @@ def test_file_channel_hands_rank0s_bytes_to_the_other_ranks(tmp_path):
 
 def test_gemm_tune_table_round_trips_through_its_int32_block():
     """rank 0's GEMM autotune decisions travel to the other ranks as a fixed int32 block through the step's own all-gather
-    (parallel.encode_tune_table / decode_tune_table): None (library GEMM) and every 5-tuple survive."""
+    (parallel.encode_tune_table / decode_tune_table): None (library GEMM) and every (mb, bn, S, mt, nt, ring) tuple survive."""
     from lookaheaddecoding_amd.parallel import decode_tune_table, encode_tune_table
     names, classes = ("wqkv", "wo", "wgu", "wd"), (32, 64, 96, 128, 192, 256)
     table = {f"{n}:{m}": None for n in names for m in classes}
-    table["wqkv:64"] = (1, 128, 5, 1, 0)
-    table["wgu:64"] = (2, 96, 1, 1, 1)
-    table["wd:256"] = (8, 128, 2, 4, 2)
+    table["wqkv:64"] = (1, 128, 5, 1, 0, 4)
+    table["wgu:64"] = (2, 96, 1, 1, 1, 6)
+    table["wd:256"] = (8, 128, 2, 4, 2, 3)
     words = encode_tune_table(table, names, classes)
-    assert len(words) == 6 * len(names) * len(classes) and all(isinstance(w, int) for w in words)
+    assert len(words) == 7 * len(names) * len(classes) and all(isinstance(w, int) for w in words)
     assert decode_tune_table(words, names, classes) == table

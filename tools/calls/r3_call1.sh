@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, GPU call 1: XCD census / hand-off probe, the new pin tests, the whole GPU suite, attention A/B + timeline
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/r3
 mkdir -p $OUT

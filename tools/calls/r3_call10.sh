@@ -1,7 +1,7 @@
 #!/bin/bash
 # K-tile-major weight layout probe
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r3
 export TMPDIR=/tmp
 timeout 400 python tools/gemm_ktile_probe.py 7b 60 30 120 > gpurun_out/r3/gemm_ktile_probe.txt 2>&1; echo "probe rc=$?"

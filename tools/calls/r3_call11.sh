@@ -1,7 +1,7 @@
 #!/bin/bash
 # K-tile-major copies in the engine: new tests, then the c2 bench line with and without them
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r3
 export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_gpu_ktile.py -x -q 2>&1 | tail -5

@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r3
 export TMPDIR=/tmp
 timeout 500 python tools/lm_head_probe.py > gpurun_out/r3/lm_head_probe.txt 2>&1; echo "lm_head probe rc=$?"; grep -v "^      " gpurun_out/r3/lm_head_probe.txt

@@ -1,7 +1,7 @@
 #!/bin/bash
 # the four bench lines again (bench.py's step-time difference now comes from alternating block pairs); kernels unchanged since make_profiles_r3.sh
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 OUT=gpurun_out/r3
 mkdir -p $OUT
 export TMPDIR=/tmp

@@ -1,7 +1,7 @@
 #!/bin/bash
 # kernel trace of the 70B-shape bench line (weights K-tile-major only)
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/r3
 mkdir -p $OUT

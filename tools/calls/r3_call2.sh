@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, GPU call 2: in-launch split merge - parity + stress tests, whole GPU suite, A/B against the two-launch merge
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/r3
 mkdir -p $OUT

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, GPU call 3: ticket-based in-launch merge - tests, in-step cost of both merge forms, isolated A/B, timeline
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/r3
 mkdir -p $OUT

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, GPU call 4: slimmed attention prologue / tail - suite, in-step cost, bench line with the new fields
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/r3
 mkdir -p $OUT

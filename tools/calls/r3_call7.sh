@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, GPU call 7: new LP test, sampling trace (no sort / topk), LP collective latency under rocprofv3, c5 + c2 lines with traffic
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/r3
 mkdir -p $OUT

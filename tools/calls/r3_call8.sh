@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, GPU call 8: flakiness of the 2-rank gloo generate() test (faulthandler armed), the LP collective inside the step under rocprofv3
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/r3
 mkdir -p $OUT

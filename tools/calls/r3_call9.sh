@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, GPU call 9: GEMM ring depth A/B (default 3 stages vs up to 5 / 8), split and unsplit, with the engine's own autotune on top
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/r3
 mkdir -p $OUT

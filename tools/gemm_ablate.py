@@ -25,6 +25,6 @@ for name, N, K, cfgs in (("qkv", 12288, 4096, [(MB, 128, 5), (MB, 256, 4), (MB, 
         part = torch.empty(S, M, N, dtype=torch.float32, device="cuda")
         def mine():
             i[0] = (i[0] + 1) % len(ws)
-            call('lade_gemm_skinny', ptr(a), a.stride(0), ptr(ws[i[0]]), ws[i[0]].stride(0), None, 0, ptr(part), M, N, K, S, bn, mb, 0, 0, 0, dtype_code(a))
+            call('lade_gemm_skinny', ptr(a), a.stride(0), ptr(ws[i[0]]), ws[i[0]].stride(0), None, 0, ptr(part), M, N, K, S, bn, mb, 0, 0, 0, 0, dtype_code(a))
         t = timeit(mine)
         print(f"dbg={dbg:>2s} {name:8s} bn={bn:3d} S={S:2d}  {t:7.2f} us  {N * K * 2 / t / 1e6:5.2f} TB/s", flush=True)

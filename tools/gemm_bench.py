@@ -59,7 +59,7 @@ for M in [int(x) for x in os.environ.get('M', '60,120').split(',')]:
                     i[0] = (i[0] + 1) % len(ws)
                     if NO_REDUCE and S > 1:
                         from lookaheaddecoding_amd.cabi import call, ptr, dtype_code
-                        call('lade_gemm_skinny', ptr(a), a.stride(0), ptr(ws[i[0]]), ws[i[0]].stride(0), ptr(out), out.stride(0), ptr(part), M, N, K, S, bn, mb, MT, NTW, 0, dtype_code(a))
+                        call('lade_gemm_skinny', ptr(a), a.stride(0), ptr(ws[i[0]]), ws[i[0]].stride(0), ptr(out), out.stride(0), ptr(part), M, N, K, S, bn, mb, MT, NTW, 0, 0, dtype_code(a))
                     else:
                         ops.gemm_skinny(a, ws[i[0]], out=out, n_split=S, bn=bn, part=part, mb=mb, mt=MT, nt=NTW)
 

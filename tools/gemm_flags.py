@@ -46,7 +46,7 @@ for name, (N, K, mb, mt, bn, nt, S) in CFG.items():
 
     def mine():
         i[0] = (i[0] + 1) % len(ws)
-        call("lade_gemm_skinny", ptr(a), a.stride(0), ptr(ws[i[0]]), ws[i[0]].stride(0), None, 0, ptr(part), M, N, K, S, bn, mb, mt, nt, 0, dtype_code(a))
+        call("lade_gemm_skinny", ptr(a), a.stride(0), ptr(ws[i[0]]), ws[i[0]].stride(0), None, 0, ptr(part), M, N, K, S, bn, mb, mt, nt, 0, 0, dtype_code(a))
 
     t = timeit(mine)
     tot += t

@@ -44,7 +44,7 @@ for name, N, K, S, bn, mb, mt, nt, epi in (("qkv", 12288, 4096, 4, 192, 2, 2, 0,
     def mine():
         i[0] = (i[0] + 1) % len(ws)
         call("lade_gemm_skinny", ptr(a), a.stride(0), ptr(ws[i[0]]), ws[i[0]].stride(0), ptr(out) if S == 1 else None, out.stride(0) if S == 1 else 0,
-             ptr(part), M, N, K, S, bn, mb, mt, nt, epi, dtype_code(a))
+             ptr(part), M, N, K, S, bn, mb, mt, nt, 0, epi, dtype_code(a))
 
     t = timeit(mine)
     wg = -(-N // bn) * S

@@ -37,7 +37,7 @@ for name, N, K, M in (("qkv-7B", 12288, 4096, 60), ("qkv-13B", 15360, 5120, 120)
         def mine():
             i[0] = (i[0] + 1) % len(ws)
             call("lade_gemm_skinny", ptr(a), a.stride(0), ptr(ws[i[0]]), ws[i[0]].stride(0), ptr(out) if S == 1 else None, out.stride(0) if S == 1 else 0,
-                 ptr(part) if S > 1 else None, M, N, K, S, bn, mb, mt, nt, 0, dtype_code(a))
+                 ptr(part) if S > 1 else None, M, N, K, S, bn, mb, mt, nt, 0, 0, dtype_code(a))
         try:
             t = timeit(mine)
             print(f"{name} M={M} S={S} bn={bn} mb={mb} mt={mt} nt={nt}: {t:6.2f} us {N * K * 2 / t / 1e6:5.2f} TB/s  ({N // bn * S} work-groups)", flush=True)

@@ -23,7 +23,7 @@ for name, N, K in (("qkv", 12288, 4096), ("gate_up", 22016, 4096)):
     for (S, bn, mb, mt, nt) in ((4, 192, 2, 2, 0), (1, 96, 2, 1, 1), (1, 96, 2, 2, 1), (2, 96, 2, 1, 1), (2, 96, 2, 2, 1), (3, 96, 2, 2, 1), (1, 128, 2, 1, 0), (2, 128, 2, 2, 0), (2, 192, 2, 2, 0)):
         def mine():
             i[0] = (i[0] + 1) % len(ws)
-            call("lade_gemm_skinny", ptr(a), a.stride(0), ptr(ws[i[0]]), ws[i[0]].stride(0), ptr(out), out.stride(0), ptr(part), M, N, K, S, bn, mb, mt, nt, 0, dtype_code(a))
+            call("lade_gemm_skinny", ptr(a), a.stride(0), ptr(ws[i[0]]), ws[i[0]].stride(0), ptr(out), out.stride(0), ptr(part), M, N, K, S, bn, mb, mt, nt, 0, 0, dtype_code(a))
         try:
             t = timeit(mine)
             print(f"{name} S={S} bn={bn} mb={mb} mt={mt}: {t:6.2f} us {N*K*2/t/1e6:5.2f} TB/s", flush=True)
