@@ -17,7 +17,25 @@
 #include <mutex>
 #include <string>
 
-#include <rccl/rccl.h>        // types, enums and prototypes only: the entry points are resolved at run time (see above), nothing links librccl
+// types, enums and prototypes only: the entry points are resolved at run time (see above), nothing links librccl.  A build box
+// without the RCCL headers still builds the library: the handful of declarations used here are then restated (NCCL's stable C API).
+#include <hip/hip_runtime.h>
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1, ncclInt32 = 2, ncclInt = 2 } ncclDataType_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId* uniqueId);
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId commId, int rank);
+ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclCommCount(const ncclComm_t comm, int* count);
+const char* ncclGetErrorString(ncclResult_t result);
+}
+#endif
 
 #include "common.hpp"
 

@@ -254,12 +254,16 @@ def _run(self, input_ids, do_sample, warp, stopping_criteria, eos_token_id, gene
     dec = getattr(self, "_lade_decoder", None)
     if dec is None or getattr(dec, "_key", None) != key or dec.e is not eng:
         lp = None
-        force_lp = bool(CONFIG_MAP.get("FORCE_LP", 0))       # one rank on the lookahead-parallel path (its collective is a 1-rank RCCL all-gather)
+        force_lp = bool(CONFIG_MAP.get("FORCE_LP", 0))       # one rank on the lookahead-parallel path (its collective: a device copy, or a 1-rank RCCL all-gather in a joined group / with LADE_LP_COLLECTIVE=abi)
         if R > 1 or force_lp:
             from .parallel import LPContext
             lp = LPContext(rank=CONFIG_MAP.get("LOCAL_RANK", 0), world=R, force=force_lp)
-        # under lookahead parallelism the rank-local part of a steady step replays as a hipGraph segment (parallel.HipLPBackend)
-        dec = LookaheadDecoder(eng, W, N, G, pool_from_prompt=key[3], lp=lp, use_graph=bool(int(os.environ.get("LADE_GRAPH", "1"))))
+        # under lookahead parallelism the rank-local part of a steady step can replay as a hipGraph segment (parallel.HipLPBackend).
+        # With more than one rank that path has only ever run as threads / gloo processes sharing one GPU (no multi-GPU box was
+        # available to any round): it stays opt-in (LADE_LP_GRAPH=1) until it has run on separate devices; the eager LP step is
+        # GPU bound anyway (4.55 vs 4.59 ms at the 7B shape).  One rank (and plain decoding) replays graphs by default.
+        graph = bool(int(os.environ.get("LADE_GRAPH", "1"))) and (R == 1 or bool(int(os.environ.get("LADE_LP_GRAPH", "0"))))
+        dec = LookaheadDecoder(eng, W, N, G, pool_from_prompt=key[3], lp=lp, use_graph=graph)
         dec._key = key
         self._lade_decoder = dec
     # per-step output like the reference: decoded text printed incrementally under CHAT=1 (lade/decoding.py:1179-1195),

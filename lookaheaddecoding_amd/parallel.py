@@ -368,6 +368,11 @@ class LPRunner:
             if os.environ.get("LADE_LP_COLLECTIVE", "torch") == "abi":
                 self.comm = RcclComm(self.lp.rank, self.lp.R)
                 all_gather = self.comm.all_gather
+            elif self.lp.R == 1 and not (dist.is_available() and dist.is_initialized()):
+                # one rank and no process group (CONFIG_MAP["FORCE_LP"] on a single GPU; the reference joins no group when
+                # DIST_WORKERS == 1, lade/utils.py:28-33): the gather of one record is a device copy on the step's stream - which is
+                # also all RCCL does for one rank (profiles/r3_lp_collective_kernels.txt)
+                all_gather = lambda out, inp: out.copy_(inp)
             else:
                 all_gather = lambda out, inp: dist.all_gather_into_tensor(out, inp, group=self.lp.group)
         self.all_gather = all_gather
