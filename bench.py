@@ -583,10 +583,13 @@ def worker(args):
                        "parallelism": f"lp{world}" if use_lp else "single", "collective_ranks": collective_ranks, "collective": collective_kind,
                        "tokens_per_step_T": round(avg_T, 1), "kv_len_end": P_end,
                        "hipgraph": bool(dec.use_graph),
-                       "weight_layout": ("projection weights held K-tile-major only (a second copy does not fit the HBM): decode GEMMs stream them, the prefill's "
+                       "weight_layout": ("projection weights held K-tile-major only: decode GEMMs stream them, the prefill's "
                                          "library GEMMs get a row-major operand rebuilt per layer" if eng.ktile_only else
-                                         f"decode GEMMs stream a K-tile-major copy of the projection weights (+{eng.ktile_bytes / 1e9:.1f} GB of HBM); "
-                                         "prefill uses the row-major ones" if eng.ktile else "row-major (LADE_W_KTILE=0)"),
+                                         (f"decode GEMMs stream K-tile-major projection weights; a second copy of all of them does not fit the HBM, the row-major originals of "
+                                          f"{eng.rows_kept} of {eng.rows_total} projections are kept for the prefill's library GEMMs (+{eng.ktile_bytes / 1e9:.1f} GB), the rest are rebuilt per chunk"
+                                          if eng.rows_kept < eng.rows_total else
+                                          f"decode GEMMs stream a K-tile-major copy of the projection weights (+{eng.ktile_bytes / 1e9:.1f} GB of HBM); "
+                                          "prefill uses the row-major ones") if eng.ktile else "row-major (LADE_W_KTILE=0)"),
                        **({"shared_gpu": True, "backend": backend} if share_gpu else {})},
             "step_compression": round(S, 3), "steps_per_s": round(args.steps / elapsed, 2), "spread": spread,
             "prefill": {"tokens": args.prompt_len + W + N - 3, "ms": round(prefill_s * 1e3, 2), "tokens_per_s": round((args.prompt_len + W + N - 3) / prefill_s, 1),
@@ -612,8 +615,13 @@ def worker(args):
             tot_us, tot_b = sum(v["us"] for v in proj.values()), sum(eng.gemm_times[(nm, cls_T)][1] for nm in proj)
             out["projections"] = {"row_class": cls_T, "weight_layout": "k-tile-major" if eng.ktile else "row-major", **proj,
                                   "layer_sum_us": round(tot_us, 2), "layer_tb_per_s": round(tot_b / tot_us / 1e6, 2),
-                                  "note": "per layer, as timed by the engine's autotune for the kernels it chose (mb, bn, n_split, mt, nt); gate/up includes SwiGLU "
+                                  "note": "per layer, as timed by the engine's autotune for the kernels it chose (mb, bn, n_split, mt, nt, ring: 0 = default depth); gate/up includes SwiGLU "
                                           "(fused epilogue when n_split = 1, else + the tuner's estimate of the SwiGLU kernel)"}
+            if eng.step_tune_log.get(cls_T):
+                # the decisions re-taken inside a step (StepEngine._refine_in_step): per projection, what the isolated pass had chosen, what
+                # the in-step pass chose, and the per-layer time of an 8-layer hipGraph forward with either
+                out["projections"]["in_step_tuning"] = {k: {kk: (list(vv) if isinstance(vv, tuple) else vv) for kk, vv in v.items()}
+                                                        for k, v in eng.step_tune_log[cls_T].items()}
     if use_lp:
         dist.barrier()
         dist.destroy_process_group()

@@ -74,6 +74,19 @@ extern "C" {
 #define LADE_MAX_LEVEL 16        /* N  (n-gram size) */
 #define LADE_MAX_WINDOW 128      /* W + N - 3 */
 #define LADE_MAX_GUESS_SET 64    /* G  (candidates per key; one wave lane per slot) */
+#define LADE_REC_WORDS (8 + LADE_MAX_LEVEL)      /* int32 words of a step's record */
+/* Seal of a step record (its last word), so that a host polling a pinned copy can tell a complete record of step `step_no` from a stale
+ * or half-landed one: a multiplicative hash of the step number xor-folded with the other words, each times an odd constant. */
+#if defined(__HIPCC__)
+#define LADE_HOST_DEVICE __host__ __device__
+#else
+#define LADE_HOST_DEVICE
+#endif
+static inline LADE_HOST_DEVICE uint32_t lade_record_seal(const uint32_t* rec, uint32_t step_no) {
+    uint32_t x = step_no * 0x9E3779B1u + 0x7F4A7C15u;
+    for (uint32_t w = 0; w + 1 < LADE_REC_WORDS; ++w) x ^= (rec[w] + w) * (2u * w + 0x85EBCA6Bu);
+    return x;
+}
 
 /* ---- control block ------------------------------------------------------------------
  * One int32 array in HBM carries the dynamic state of a sequence between kernels, so a steady
@@ -214,7 +227,10 @@ int lade_window_roll(int32_t* window, int32_t wcap, int32_t* ctl, const int32_t*
  * -> window fill / roll -> EOS scan + POOL_FROM_PROMPT appends (`tail` = [len, last <=N tokens of the
  * reference's all_old_tokens]) -> lookup of the next step's candidates into `guess` / ctl[G] -> ctl update
  * (P, lst_token, lst_pos, kv-commit triple, hits, step).
- * record = {max_hit, n_accept, finished_by_eos, g_next, P_next, max_hit_idx, first_guess, -, hits[gs]}.
+ * record = {max_hit, n_accept, finished_by_eos, g_next, P_next, max_hit_idx, first_guess, step number (ctl[STEP] after this step),
+ * hits[gs], 0 ..., seal} - LADE_REC_WORDS words, the last one lade_record_seal() of the others.  record_host (nullable): the same
+ * words are ALSO stored to this address - pinned host memory mapped into the device - followed by a system-scope fence, so that the
+ * host can poll for the step's record instead of synchronising the stream (no copy node, no blocking wait in a steady step).
  * eos < 0 disables the EOS scan; the scan follows lade/decoding.py:1167-1177.
  * Sampling (lade/decoding.py:137-692): the rejection-sampling verify runs on the host (it consumes the python
  * and torch RNG streams in the reference's order); its result is passed as forced = {max_hit, max_hit_idx,
@@ -224,7 +240,7 @@ int lade_greedy_post_step(int32_t* ctl, int32_t* window, int32_t wcap, int32_t* 
                           int32_t V, int32_t W, int32_t N, int32_t G, const int32_t* am, int32_t n_inp,
                           int32_t* guess, int32_t T_step, int32_t cand_rows, int32_t phase, int32_t pool_from_prompt,
                           int32_t* tail, int32_t eos, const int32_t* forced, const int32_t* level_override,
-                          int32_t* record, void* stream);
+                          int32_t* record, int32_t* record_host, void* stream);
 
 /* lookahead parallelism: record packing, then (after the all-gather of rec_words int32 per rank, lade_lp_allgather
  * or the host's collective) the deterministic reduction every rank applies (same phases as above).
@@ -316,7 +332,7 @@ int lade_gather_rows(const void* src, const int32_t* idx, void* dst, int32_t row
  * order - deterministic - by lade_splitk_reduce).  bn = weight rows per work-group (32..256), mb = 32-row activation
  * blocks per work-group (1: 32 rows, 2: 64, 3: 96, 4: 128, 0: by M; larger M runs as several row blocks).  mt = 32-row activation blocks per WAVE (0 | 1..4, divides
  * mb) and nt = 32-row weight tiles per wave (0 = fewest): the waves form an (mb/mt) x (bn/32/nt) grid; larger wave tiles
- * re-read less from LDS per weight byte.  ring = stages of the LDS ring the tiles arrive in (0 = default: 4 where they fit; 2..8): a
+ * re-read less from LDS per weight byte.  ring = stages of the LDS ring the tiles arrive in (0 = default: 4 where they fit; 2, 3, 4, 5, 6, 8): a
  * deeper ring keeps more bytes in flight per work-group and leaves room for fewer co-resident work-groups - chosen per projection by the
  * caller's autotune.  Unsupported shapes return LADE_E_ARG.  K % 64 == 0.  M > 256 runs as several 256-row blocks per launch (bn = 256,
  * mb = 8, nt = 2 | 4 is a compute-shaped 256 x 256 tile on a double buffer).

@@ -28,6 +28,15 @@ MAX_LEVEL, MAX_WINDOW, MAX_GUESS_SET = 16, 128, 64
 REC_WORDS = 8 + MAX_LEVEL
 
 
+def record_seal(rec, step_no: int) -> int:
+    """lade_record_seal of include/lade_hip.h on the host: the last word of a step record as the device computes it (32-bit wrap-around)"""
+    M = 0xFFFFFFFF
+    x = ((step_no & M) * 0x9E3779B1 + 0x7F4A7C15) & M
+    for w in range(REC_WORDS - 1):
+        x ^= ((((rec[w] & M) + w) & M) * ((2 * w + 0x85EBCA6B) & M)) & M
+    return x
+
+
 class LadeHipError(RuntimeError):
     pass
 
@@ -67,7 +76,7 @@ SIGNATURES = {
     "lade_window_fill": [_vp, _i32, _vp, _i32, _vp, _i32, _vp],
     "lade_window_roll": [_vp, _i32, _vp, _vp, _i32, _i32, _vp],
     "lade_greedy_post_step": [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp,
-                              _i32, _vp, _vp, _vp, _vp],
+                              _i32, _vp, _vp, _vp, _vp, _vp],
     "lade_lp_pack": [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _vp],
     "lade_lp_reduce_apply": [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp],
     "lade_lp_unique_id": [_vp],

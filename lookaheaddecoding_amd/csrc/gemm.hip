@@ -63,6 +63,7 @@ static int gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, b
                        int32_t M, int32_t N, int32_t K, int32_t n_split, int32_t bn, int32_t mb, int32_t mt, int32_t nt, int32_t ring,
                        int32_t epilogue, int32_t dtype, void* stream) {
     LADE_REQUIRE(ring == 0 || (ring >= 2 && ring <= 8), LADE_E_ARG, "lade_gemm_skinny: ring=%d (0 = default, 2..8 stages)", ring);
+    LADE_REQUIRE(ring != 7, LADE_E_ARG, "lade_gemm_skinny: no loop is compiled for a ring of 7 stages (2, 3, 4, 5, 6, 8 are)");
     LADE_REQUIRE(epilogue == 0 || (epilogue == 1 && n_split == 1 && N % 32 == 0 && C != nullptr), LADE_E_ARG,
                  "lade_gemm_skinny: epilogue=%d needs n_split == 1, N %% 32 == 0 and an output matrix", epilogue);
     LADE_REQUIRE(A && W && M > 0 && N > 0 && K > 0 && n_split >= 1, LADE_E_ARG, "lade_gemm_skinny: M=%d N=%d K=%d split=%d", M, N, K, n_split);

@@ -2,6 +2,8 @@
 // unit per dtype, so that the instantiations compile in parallel); gemm.hip holds the C entry points.
 #pragma once
 #include "common.hpp"
+#include <type_traits>
+
 #include "gemm_decl.hpp"
 
 namespace lade {
@@ -77,8 +79,6 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
     constexpr int W_PIECES = W_BYTES / 1024, A_PIECES = A_BYTES / 1024;      // 1-KiB DMA pieces per tile
     constexpr int TOTAL_PIECES = W_PIECES + A_PIECES;
     constexpr int PIECES = (TOTAL_PIECES + NW - 1) / NW;                     // per wave and stage (the tail repeats the last piece)
-    const int NS = g.n_stage;                                                // ring depth of this launch (host-validated against the LDS)
-
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -136,8 +136,6 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
                                                  (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     };
-    for (int s = 0; s < NS; ++s)
-        if (s < nt) issue(s, s);
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -147,32 +145,48 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][i][e] = 0.f;
 
-    int stage = 0;
-    for (int i = 0; i < nt; ++i) {
-        const int younger = min(nt, i + NS) - (i + 1);        // tiles requested after tile i that may stay in flight
-        g_wait_younger<PIECES, G_NSTAGE_CAP - 1>(younger);
-        g_barrier();
-        const unsigned char* ws = smem + stage * STAGE;
-        const unsigned char* as = ws + W_BYTES;
-        if (computes && !(g.dbg & 4))
+    // The ring depth is a launch parameter, but the loop is compiled once per depth (the counted waits need immediates, and a run-time
+    // chain of compare-and-branch per K tile in front of every barrier cost the step 6 %: 4.29 / 4.33 vs 4.05 / 4.10 ms against the
+    // compile-time ring on one box); the kernel switches to its copy once.
+    auto main_loop = [&](auto ns_c) __attribute__((always_inline)) {
+        constexpr int NS = decltype(ns_c)::value;
 #pragma unroll
-        for (int kk = 0; kk < G_BK / 16; ++kk) {
-            u32x4 af[MT], wf[NT];
-#pragma unroll
-            for (int a = 0; a < MT; ++a) af[a] = *reinterpret_cast<const u32x4*>(as + g_off((mw * MT + a) * 32 + ql, kk * 2 + hi));
-#pragma unroll
-            for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const u32x4*>(ws + g_off((ng * NT + j) * 32 + ql, kk * 2 + hi));
-#pragma unroll
-            for (int a = 0; a < MT; ++a)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[a][j] = GMfma<T>::run(wf[j], af[a], acc[a][j]);
-        }
-        if (i + NS < nt) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int s = 0; s < NS; ++s)
+            if (s < nt) issue(s, s);
+        for (int i = 0; i < nt; ++i) {
+            const int stage = i % NS;
+            const int younger = min(nt, i + NS) - (i + 1);        // tiles requested after tile i that may stay in flight
+            g_wait_younger<PIECES, NS - 1>(younger);
             g_barrier();
-            issue(i + NS, stage);
+            const unsigned char* ws = smem + stage * STAGE;
+            const unsigned char* as = ws + W_BYTES;
+            if (computes && !(g.dbg & 4))
+#pragma unroll
+            for (int kk = 0; kk < G_BK / 16; ++kk) {
+                u32x4 af[MT], wf[NT];
+#pragma unroll
+                for (int a = 0; a < MT; ++a) af[a] = *reinterpret_cast<const u32x4*>(as + g_off((mw * MT + a) * 32 + ql, kk * 2 + hi));
+#pragma unroll
+                for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const u32x4*>(ws + g_off((ng * NT + j) * 32 + ql, kk * 2 + hi));
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[a][j] = GMfma<T>::run(wf[j], af[a], acc[a][j]);
+            }
+            if (i + NS < nt) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                g_barrier();
+                issue(i + NS, stage);
+            }
         }
-        stage = stage + 1 == NS ? 0 : stage + 1;
+    };
+    switch (g.n_stage) {
+        case 2: main_loop(std::integral_constant<int, 2>{}); break;
+        case 3: main_loop(std::integral_constant<int, 3>{}); break;
+        case 5: main_loop(std::integral_constant<int, 5>{}); break;
+        case 6: main_loop(std::integral_constant<int, 6>{}); break;
+        case 8: main_loop(std::integral_constant<int, 8>{}); break;
+        default: main_loop(std::integral_constant<int, 4>{}); break;
     }
 
     // ---- epilogue: C^T tile (lane = activation row ql of block mb, 16 weight rows per MFMA tile) -> row-major C ----
@@ -297,7 +311,7 @@ static int launch_gemm(const GemmK& g0, hipStream_t st) {
     constexpr size_t STAGE = (size_t)(BN + BM) * 128;
     GemmK g = g0;
     if (g.n_stage == 0) g.n_stage = g_stages(BN, BM);
-    LADE_REQUIRE(g.n_stage >= 2 && g.n_stage <= G_NSTAGE_CAP && g.n_stage * STAGE <= (size_t)G_LDS_MAX, LADE_E_ARG,
+    LADE_REQUIRE(g.n_stage >= 2 && g.n_stage <= G_NSTAGE_CAP && g.n_stage != 7 && g.n_stage * STAGE <= (size_t)G_LDS_MAX, LADE_E_ARG,
                  "lade_gemm_skinny: a ring of %d stages of %d + %d rows does not fit the %d KB of LDS", g.n_stage, BN, BM, G_LDS_MAX / 1024);
     // the epilogue stages the [BM][BN] tile through the LDS (model dtype without split-K, fp32 partials with it); an fp32 tile larger
     // than the LDS (the 256 x 256 shape) is stored straight from the accumulators instead

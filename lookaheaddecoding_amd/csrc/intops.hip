@@ -60,6 +60,94 @@ __device__ void pool_insert_window(int32_t* pool_tok, int32_t* pool_cnt, int V, 
     }
 }
 
+// ---- the same W inserts with the pool rows staged in LDS (round 4) ---------------------------------------------------------
+// pool_insert_window is W dependent round trips to the pool in global memory: count, compare, shift, store - ~1 us each, 15.8 us of
+// the 7B step's tail.  The keys of a step are known up front (lst_token and level 0 of the window), so the count and the G x gs row of
+// every DISTINCT key are requested at once (one memory latency), the W sequential inserts - column order, duplicate keys sharing one
+// staged row: the order the reference's python list sees - run on LDS, and the rows go back in one sweep.  Columns are taken in chunks
+// that fit the staging area (W = 60, G = 60, N = 8: four chunks); a chunk is written back before the next one loads, so the
+// sequential semantics hold across chunks too.  Bit-exact against lru_insert (tests: the 99 reference pool states, churn at the ABI
+// limits, every golden end-to-end trace).
+constexpr int STG_ROW_INTS = 8192;          // 32 KB of pool rows
+
+// one insert on a staged row: the body of lru_insert on LDS (single wavefront: lane = slot)
+__device__ __forceinline__ void lru_insert_row(int32_t* slots, int32_t* cnt_p, int G, int gs, const int32_t* tup) {
+    const int lane = threadIdx.x;
+    const int cnt = *cnt_p;
+    bool match = lane < cnt;
+    for (int j = 0; j < gs && match; ++j) match = slots[lane * gs + j] == tup[j];
+    const uint64_t ball = __ballot(match);
+    __syncthreads();
+    if (ball == 0ull && cnt < G) {                       // append
+        if (lane < gs) slots[cnt * gs + lane] = tup[lane];
+        if (lane == 0) *cnt_p = cnt + 1;
+    } else {                                             // hit: move to the end; full without hit: drop the head
+        const int from = ball ? (__ffsll((unsigned long long)ball) - 1) : 0;
+        int32_t mv[LADE_MAX_LEVEL];
+        const bool shifts = lane >= from && lane + 1 < cnt;
+#pragma unroll
+        for (int j = 0; j < LADE_MAX_LEVEL; ++j)
+            if (shifts && j < gs) mv[j] = slots[(lane + 1) * gs + j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < LADE_MAX_LEVEL; ++j)
+            if (shifts && j < gs) slots[lane * gs + j] = mv[j];
+        if (lane < gs) slots[(cnt - 1) * gs + lane] = tup[lane];
+    }
+    __syncthreads();
+}
+
+struct PoolStage {
+    int32_t key[LADE_MAX_WINDOW];
+    int32_t own[LADE_MAX_WINDOW];          // chunk column whose staged row serves this column (the first one with the same key); -1: no valid key
+    int32_t cnt[LADE_MAX_WINDOW];
+    int32_t rows[STG_ROW_INTS];
+};
+
+// win: the window BEFORE the roll ([N-1][wcap], LDS or global); new_results [W]
+__device__ void pool_insert_window_staged(int32_t* pool_tok, int32_t* pool_cnt, int V, int G, int gs, int lst_token, const int32_t* win,
+                                          int wcap, const int32_t* new_results, int W, int N, int32_t* tup_sm, PoolStage& st) {
+    const int lane = threadIdx.x;
+    if (G <= 0) return;
+    const int row_ints = G * gs;
+    const int C = min(W, STG_ROW_INTS / row_ints);       // G <= 64, gs <= 15: at least 8 columns per chunk
+    for (int c0 = 0; c0 < W; c0 += C) {
+        const int n = min(C, W - c0);
+        for (int i = lane; i < n; i += 64) st.key[i] = (c0 + i == 0) ? lst_token : win[c0 + i - 1];
+        __syncthreads();
+        for (int i = lane; i < n; i += 64) {
+            const int key = st.key[i];
+            int own = -1;
+            if (key >= 0 && key < V) {
+                own = i;
+                for (int j = 0; j < i; ++j)
+                    if (st.key[j] == key) { own = j; break; }
+            }
+            st.own[i] = own;
+            if (own == i) st.cnt[i] = pool_cnt[key];
+        }
+        __syncthreads();
+        for (int idx = lane; idx < n * row_ints; idx += 64) {          // every row load of the chunk in flight together
+            const int i = idx / row_ints, e = idx - i * row_ints;
+            if (st.own[i] == i) st.rows[idx] = pool_tok[(size_t)st.key[i] * row_ints + e];
+        }
+        __syncthreads();
+        for (int i = 0; i < n; ++i) {
+            if (lane < gs) tup_sm[lane] = (lane < gs - 1) ? win[(lane + 1) * wcap + c0 + i] : new_results[c0 + i];
+            __syncthreads();
+            const int own = st.own[i];
+            if (own >= 0) lru_insert_row(st.rows + own * row_ints, &st.cnt[own], G, gs, tup_sm);
+        }
+        for (int idx = lane; idx < n * row_ints; idx += 64) {
+            const int i = idx / row_ints, e = idx - i * row_ints;
+            if (st.own[i] == i && e < st.cnt[i] * gs) pool_tok[(size_t)st.key[i] * row_ints + e] = st.rows[idx];
+        }
+        for (int i = lane; i < n; i += 64)
+            if (st.own[i] == i) pool_cnt[st.key[i]] = st.cnt[i];
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(64) void pool_insert_window_kernel(int32_t* pool_tok, int32_t* pool_cnt, int V, int G, int gs,
                                                                 const int32_t* lst_token, const int32_t* window, int wcap,
                                                                 const int32_t* new_results, int W, int N) {
@@ -86,7 +174,11 @@ __device__ int pool_lookup(const int32_t* pool_tok, const int32_t* pool_cnt, int
     int cnt = 0;
     if (key >= 0 && key < V && G > 0) cnt = pool_cnt[key];
     const int32_t* slots = pool_tok + (size_t)(key >= 0 && key < V ? key : 0) * G * gs;
-    for (int idx = threadIdx.x; idx < G * gs; idx += blockDim.x) guess_out[idx] = idx < cnt * gs ? slots[idx] : 0;
+    // the row is read whatever the count says (any valid key's row is in bounds): count and row travel together, one memory latency
+    for (int idx = threadIdx.x; idx < G * gs; idx += blockDim.x) {
+        const int32_t v = slots[idx];
+        guess_out[idx] = idx < cnt * gs ? v : 0;
+    }
     return cnt;
 }
 
@@ -104,11 +196,17 @@ __device__ void verify_greedy(int first_guess, const int32_t* guess, const int32
     const int lane = threadIdx.x;
     int gg = 0;
     if (lane < g) {
-        gg = gs - 1;
-        for (int j = 0; j < gs; ++j) {
-            const int correct = (j == 0) ? first_guess : guess_argmax[lane * gs + j - 1];
-            if (guess[lane * gs + j] != correct) { gg = j; break; }
+        // every load of the candidate first (a break inside the loop made them gs dependent memory latencies), then the comparison
+        int32_t gv[LADE_MAX_LEVEL], cv[LADE_MAX_LEVEL];
+#pragma unroll
+        for (int j = 0; j < LADE_MAX_LEVEL; ++j) {
+            gv[j] = j < gs ? guess[lane * gs + j] : 0;
+            cv[j] = (j == 0) ? first_guess : (j < gs ? guess_argmax[lane * gs + j - 1] : 0);
         }
+        gg = gs - 1;
+#pragma unroll
+        for (int j = LADE_MAX_LEVEL - 1; j >= 0; --j)
+            if (j < gs && gv[j] != cv[j]) gg = j;
     }
     int best = gg;
     for (int o = 32; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o));
@@ -371,12 +469,21 @@ __global__ __launch_bounds__(64) void greedy_post_step_kernel(int32_t* ctl, int3
                                                               int32_t* pool_cnt, int V, int W, int N, int G, const int32_t* am,
                                                               int n_inp, int32_t* guess, int T_step, int cand_rows, int phase,
                                                               int pool_from_prompt, int32_t* tail, int eos, const int32_t* forced,
-                                                              const int32_t* level_override, int32_t* record) {
+                                                              const int32_t* level_override, int32_t* record, int32_t* record_host) {
     __shared__ int32_t tup[LADE_MAX_LEVEL];
     __shared__ int32_t hits[LADE_MAX_LEVEL];
     __shared__ int32_t ng[LADE_MAX_LEVEL + 1];
+    __shared__ int32_t rec_s[LADE_REC_WORDS];
+    __shared__ int32_t s_win[(LADE_MAX_LEVEL - 1) * LADE_MAX_WINDOW];
+    __shared__ int32_t s_new[LADE_MAX_WINDOW];
+    __shared__ PoolStage stage;
     const int gs = N - 1;
     const int lane = threadIdx.x;
+    // steady step: the window and the new level are staged in LDS while the control words arrive (independent loads, one latency)
+    if (phase == 2) {
+        for (int i = lane; i < (N - 1) * wcap; i += 64) s_win[i] = window[i];
+        for (int i = lane; i < W; i += 64) s_new[i] = am[1 + i];
+    }
     const int g = ctl[LADE_CTL_G];
     const int P = ctl[LADE_CTL_P];
     const int n_input = ctl[LADE_CTL_N_INPUT];
@@ -399,8 +506,22 @@ __global__ __launch_bounds__(64) void greedy_post_step_kernel(int32_t* ctl, int3
             verify_greedy(first_guess, guess, am_guess, g, gs, &max_hit, &max_hit_idx, hits);
             __syncthreads();
         }
-        pool_insert_window(pool_tok, pool_cnt, V, G, gs, lst_token, window, wcap, inp_am, W, N, tup);
-        window_roll(window, wcap, ctl, inp_am, W, N);
+        __syncthreads();
+        pool_insert_window_staged(pool_tok, pool_cnt, V, G, gs, lst_token, s_win, wcap, s_new, W, N, tup, stage);
+        // window roll (lade/decoding.py:1119-1124) on the staged copy, one write-back
+        for (int l = 0; l < N - 2; ++l) {
+            const int off = (l == 0) ? 1 : 0;
+            for (int i = lane; i < W - off; i += 64) s_win[l * wcap + i] = s_win[(l + 1) * wcap + i + off];
+            __syncthreads();
+        }
+        for (int i = lane; i < W; i += 64) s_win[(N - 2) * wcap + i] = s_new[i];
+        __syncthreads();
+        for (int i = lane; i < (N - 1) * wcap; i += 64) window[i] = s_win[i];
+        if (lane == 0) {
+            ctl[LADE_CTL_WLEN] = W - 1;
+            for (int l = 1; l < N - 1; ++l) ctl[LADE_CTL_WLEN + l] = W;
+        }
+        __syncthreads();
         if (level_override) {                                   // filter_window (lade/decoding.py:131-135, :578-580)
             for (int i = lane; i < W; i += 64)
                 if (level_override[i] >= 0) window[(N - 2) * wcap + i] = level_override[i];
@@ -421,6 +542,7 @@ __global__ __launch_bounds__(64) void greedy_post_step_kernel(int32_t* ctl, int3
     int g_next = 0;
     if (window_full) g_next = pool_lookup(pool_tok, pool_cnt, V, G, gs, new_lst, guess);
     __syncthreads();
+    int step_no = 0;
     if (lane == 0) {
         ctl[LADE_CTL_MAX_HIT] = max_hit;
         ctl[LADE_CTL_MAX_HIT_IDX] = max_hit_idx;
@@ -434,16 +556,29 @@ __global__ __launch_bounds__(64) void greedy_post_step_kernel(int32_t* ctl, int3
         ctl[LADE_CTL_LST_POS] = lst_pos + max_hit + 1;
         ctl[LADE_CTL_N_INPUT] = 1;
         ctl[LADE_CTL_G] = g_next;
-        ctl[LADE_CTL_STEP] += 1;
-        record[0] = max_hit;
-        record[1] = n_accept;
-        record[2] = finished;
-        record[3] = g_next;
-        record[4] = kvcache_len + max_hit;
-        record[5] = max_hit_idx;
-        record[6] = first_guess;
+        step_no = ctl[LADE_CTL_STEP] + 1;
+        ctl[LADE_CTL_STEP] = step_no;
+        rec_s[0] = max_hit;
+        rec_s[1] = n_accept;
+        rec_s[2] = finished;
+        rec_s[3] = g_next;
+        rec_s[4] = kvcache_len + max_hit;
+        rec_s[5] = max_hit_idx;
+        rec_s[6] = first_guess;
+        rec_s[7] = step_no;
     }
-    if (lane < gs) { ctl[LADE_CTL_HITS + lane] = hits[lane]; record[8 + lane] = hits[lane]; }
+    if (lane < LADE_MAX_LEVEL) rec_s[8 + lane] = lane < gs ? hits[lane] : 0;
+    if (lane < gs) ctl[LADE_CTL_HITS + lane] = hits[lane];
+    __syncthreads();
+    // the record's last word seals it: a host that POLLS its pinned copy (no stream synchronisation: the copy lands word by word) accepts
+    // the record only when the seal matches the step number it waits for and the other 23 words it has read
+    if (lane == 0) rec_s[LADE_REC_WORDS - 1] = (int32_t)lade_record_seal((const uint32_t*)rec_s, (uint32_t)step_no);
+    __syncthreads();
+    if (lane < LADE_REC_WORDS) {
+        record[lane] = rec_s[lane];
+        if (record_host) record_host[lane] = rec_s[lane];        // pinned host memory mapped into the device: visible without a copy node
+    }
+    if (record_host) __threadfence_system();
 }
 
 // ---- lookahead parallelism: one fixed int32 record per rank per step ------------------------------
@@ -651,7 +786,7 @@ extern "C" int lade_argmax_rows(const void* logits, int64_t ld, int32_t rows, in
 extern "C" int lade_greedy_post_step(int32_t* ctl, int32_t* window, int32_t wcap, int32_t* pool_tok, int32_t* pool_cnt, int32_t V,
                                      int32_t W, int32_t N, int32_t G, const int32_t* am, int32_t n_inp, int32_t* guess, int32_t T_step,
                                      int32_t cand_rows, int32_t phase, int32_t pool_from_prompt, int32_t* tail, int32_t eos,
-                                     const int32_t* forced, const int32_t* level_override, int32_t* record, void* stream) {
+                                     const int32_t* forced, const int32_t* level_override, int32_t* record, int32_t* record_host, void* stream) {
     const int gs = N - 1;
     POOL_ARGS_OK("lade_greedy_post_step");
     LADE_REQUIRE(ctl && window && am && guess && record && W > 0 && W + N - 3 <= wcap && N >= 3 && N <= LADE_MAX_LEVEL && T_step > 0 && cand_rows >= 0 &&
@@ -659,7 +794,7 @@ extern "C" int lade_greedy_post_step(int32_t* ctl, int32_t* window, int32_t wcap
                  LADE_E_ARG, "lade_greedy_post_step: W=%d N=%d wcap=%d T=%d phase=%d n_inp=%d", W, N, wcap, T_step, phase, n_inp);
     LADE_REQUIRE(!pool_from_prompt || tail, LADE_E_ARG, "lade_greedy_post_step: POOL_FROM_PROMPT needs the tail buffer");
     hipLaunchKernelGGL(greedy_post_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctl, window, wcap, pool_tok, pool_cnt, V, W, N, G,
-                       am, n_inp, guess, T_step, cand_rows, phase, pool_from_prompt, tail, eos, forced, level_override, record);
+                       am, n_inp, guess, T_step, cand_rows, phase, pool_from_prompt, tail, eos, forced, level_override, record, record_host);
     return check_launch("lade_greedy_post_step");
 }
 

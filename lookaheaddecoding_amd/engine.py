@@ -85,7 +85,11 @@ def _on_device(fn):
 
 _TUNE_CACHE: dict = {}
 _TUNE_TIMES: dict = {}
+_TUNE_RANKED: dict = {}
 _TUNE_LOCK = __import__("threading").Lock()
+_STEP_TUNE_CACHE: dict = {}
+_STEP_TUNE_LOCK = __import__("threading").Lock()
+REP_ROWS = {32: 30, 64: 60, 96: 92, 128: 128, 192: 180, 256: 240}        # the rows a row class is timed at
 
 
 class StepEngine:
@@ -150,6 +154,10 @@ class StepEngine:
         self.max_splits = 32
         self.gemm_cfg = {}
         self.gemm_times = {}                # (projection, row class) -> (ms of the chosen kernel in the autotune, weight bytes)
+        self._ranked = {}                   # (projection, row class) -> the isolated pass's candidates, fastest first [(ms, cfg | None)]
+        self._refined = set()               # row classes whose decisions were re-taken inside the step (_refine_in_step)
+        self._refining = False
+        self.step_tune_log = {}             # row class -> what the in-step pass measured (bench.py prints it)
         self._alloc_workspaces(max_T)
         try:
             self.n_cu = torch.cuda.get_device_properties(self.device.index).multi_processor_count
@@ -371,10 +379,12 @@ class StepEngine:
                 torch.cuda.get_device_name(self.device), self.n_cu, ws[1][0].dim() == 3, ws[0] is None, name == "lm_head")
         with _TUNE_LOCK:
             if gkey not in _TUNE_CACHE:
-                self._tuned_ms = None
+                self._tuned_ms, self._tuned_ranked = None, []
                 _TUNE_CACHE[gkey] = self._tune_timed(name, mclass, ws, N, K)
                 _TUNE_TIMES[gkey] = self._tuned_ms
+                _TUNE_RANKED[gkey] = self._tuned_ranked
             best = _TUNE_CACHE[gkey]
+            self._ranked[key] = _TUNE_RANKED.get(gkey, [])
             # what the winner took when it was timed (isolated launches, every launch on another layer's weights), for bench.py's report
             self.gemm_times[key] = (_TUNE_TIMES.get(gkey), int(N) * int(K) * ws[1][0].element_size())
         self.gemm_cfg[key] = best
@@ -382,7 +392,7 @@ class StepEngine:
 
     def _tune_timed(self, name: str, mclass: int, ws, N: int, K: int):
         ws_lib, ws = ws
-        a = torch.randn({32: 30, 64: 60, 96: 92, 128: 128, 192: 180, 256: 240}[mclass], K, device=self.device).to(self.dtype)
+        a = torch.randn(REP_ROWS[mclass], K, device=self.device).to(self.dtype)
         out = torch.empty(a.shape[0], N, dtype=self.dtype, device=self.device)
         if name == "lm_head":
             return self._tune_lm_head(mclass, a, out, ws_lib, ws, N, K)
@@ -455,7 +465,7 @@ class StepEngine:
         # second pass: the LDS ring depth of the best few.  More stages = more bytes in flight per work-group, fewer work-groups per CU;
         # which of the two a projection needs depends on its split count (an unsplit gate/up GEMM is one work-group per CU whatever the
         # ring costs, a 512-work-group split-K launch needs two per CU), so the depth is a per-kernel decision like the shape itself
-        if os.environ.get("LADE_TUNE_RING", "1") != "0":
+        if os.environ.get("LADE_TUNE_RING", "0") != "0":      # (off: isolated launches do not rank ring depths the way the step does - _refine_in_step decides them)
             for t0, (mb, bn, S, mt, nt, _r) in sorted(timed)[:3]:
                 stage_bytes = (bn + 32 * mb) * 128
                 for ring in (3, 5, 6, 8):
@@ -473,6 +483,7 @@ class StepEngine:
         if timed and min(timed)[0] < t_lib:
             t_best, best = min(timed)
         self._tuned_ms = t_best
+        self._tuned_ranked = sorted(timed) + ([(t_lib, None)] if ws_lib is not None else [])
         if os.environ.get("LADE_TUNE_VERBOSE"):          # tools/gemm_tune_probe.py: what the tuner saw
             mbytes = N * K * ws[0].element_size() / 1e6
             top = " ".join(f"{c}:{t * 1e3:.1f}" for t, c in sorted(timed)[:6])
@@ -513,7 +524,7 @@ class StepEngine:
                     except cabi.LadeHipError:
                         continue                      # wave grid not built for this row class
                     timed.append((t, (mbs, bn, 1, mt, nt, 0)))
-        if os.environ.get("LADE_TUNE_RING", "1") != "0":
+        if os.environ.get("LADE_TUNE_RING", "0") != "0":
             for t0, (mb, bn, S, mt, nt, _r) in sorted(timed)[:2]:
                 stage_bytes = (bn + 32 * mb) * 128
                 for ring in (3, 5, 6, 8):
@@ -534,6 +545,125 @@ class StepEngine:
                   f"({N * K * 2 / 1e6 / (t_best * 1e3):.2f} TB/s) | {top}", file=sys.stderr, flush=True)
         return best
 
+    # ---- the same decisions, re-taken inside a step ------------------------------------------------------------------------
+    STEP_TUNE_LAYERS = 8
+    STEP_TUNE_MIN_BYTES = 512 << 20
+
+    def _refine_in_step(self, mclass: int) -> None:
+        """Isolated launches do not rank GEMM configurations the way a step does: back to back on one stream a kernel meets warm caches, no
+        consumer reads its split-K partials and no glue kernel sits between it and the next weight stream.  Round 4 measured it: a
+        4-stage LDS ring took the 7B step from 3.91 / 3.86 to 3.78 / 3.77 ms (same box, alternating), while the isolated pass ranked 3
+        stages first for nearly every projection.  So after the isolated pass has produced a short list per projection, the decision is
+        re-taken where it counts: hipGraphs of a real forward over the first STEP_TUNE_LAYERS layers (weights >> the Infinity Cache, the
+        attention pair, RoPE and both norms in place, the consumers reading the partials), one graph per candidate - the short list x
+        ring depths, plus the best candidate of each smaller split count - replayed round-robin; projection after projection
+        (coordinate descent, one pass), a challenger replaces the incumbent only when it wins by > 0.3 %.  The probe step runs on the
+        last T rows of the KV cache (saved and restored) and on no live workspace.  One decision per model shape, row class and process.
+        LADE_TUNE_STEP=0 keeps the isolated pass's table."""
+        if mclass in self._refined or self._refining or not self.custom_gemm:
+            return
+        T = REP_ROWS[mclass]
+        esz = self.layers[0]["wo"].element_size() if "wo" in self.layers[0] else self.layers[0]["wo_kt"].element_size()
+        layer_bytes = esz * (self.hidden * ((self.H + 2 * self.Hkv) * self.d + self.H * self.d) + 3 * self.hidden * self.inter)
+        n_probe = min(self.L, self.STEP_TUNE_LAYERS)
+        if (os.environ.get("LADE_TUNE_STEP", "1") == "0" or layer_bytes * n_probe < self.STEP_TUNE_MIN_BYTES or T > self.max_T
+                or 2 * T > self.S_max or any((n, mclass) not in self.gemm_cfg for n in self.LAYER_GEMMS)):
+            self._refined.add(mclass)          # toy models sit in the Infinity Cache whatever runs: the isolated table stands
+            return
+        if torch.cuda.is_current_stream_capturing():
+            return                             # decided at the next eager call (the decoders warm a step up before they capture it)
+        skey = (self.hidden, self.inter, self.H, self.Hkv, self.d, self.L, mclass, str(self.dtype), torch.cuda.get_device_name(self.device),
+                self.n_cu, tuple(self.kt_names), self.gu_layout, tuple(self.gemm_cfg[(n, mclass)] for n in self.LAYER_GEMMS))
+        with _STEP_TUNE_LOCK:
+            if skey not in _STEP_TUNE_CACHE:
+                _STEP_TUNE_CACHE[skey] = self._refine_timed(mclass, T, n_probe)
+            choice, log = _STEP_TUNE_CACHE[skey]
+        for n, c in choice.items():
+            self.gemm_cfg[(n, mclass)] = c
+            ranked = dict((cfg[:5] if cfg else None, t) for t, cfg in reversed(self._ranked.get((n, mclass), [])))
+            if (n, mclass) in self.gemm_times:
+                self.gemm_times[(n, mclass)] = (ranked.get(c[:5] if c else None, self.gemm_times[(n, mclass)][0]), self.gemm_times[(n, mclass)][1])
+        self.step_tune_log[mclass] = log
+        self._refined.add(mclass)
+
+    def _step_candidates(self, name: str, mclass: int):
+        ranked = [c for _t, c in self._ranked.get((name, mclass), [])]
+        inc = self.gemm_cfg[(name, mclass)]
+        shapes = [c for c in ranked[:3] if c is not None]
+        for S in sorted({c[2] for c in ranked if c is not None})[:2]:                   # the best candidate of the two smallest split counts
+            shapes.append(next(c for c in ranked if c is not None and c[2] == S))
+        out = [inc]
+        for c in shapes:
+            stage_bytes = (c[1] + 32 * c[0]) * 128
+            dflt = min(4, 160 * 1024 // stage_bytes)
+            for ring in (0, 3, 5, 6, 8):             # (the depths the kernel is compiled for: 2, 3, 4 = default, 5, 6, 8)
+                cand = c[:5] + (ring,)
+                if (ring == 0 or (ring != dflt and ring * stage_bytes <= 160 * 1024)) and cand not in out:
+                    out.append(cand)
+        return out[:18]
+
+    def _refine_timed(self, mclass: int, T: int, n_probe: int):
+        dev = self.device
+        P = self.S_max - T
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(20240924)
+        ids = torch.randint(0, self.V, (T,), device=dev, dtype=torch.int32, generator=gen)
+        pos = torch.arange(P, P + T, device=dev, dtype=torch.int32)
+        mask = StepMask(T=T, P=P, is_prefill=True)
+        sel = torch.zeros(1, dtype=torch.int32, device=dev)
+        n_splits = self.n_splits_for(T, P + T)
+        all_layers = self.layers
+        kv_saved = [(self._k_views[li][:, P:P + T].clone(), self._vt_views[li][:, :, P:P + T].clone()) for li in range(n_probe)]
+        saved_ev, self.attn_events = self.attn_events, None
+        choice, log = {}, {}
+        self._refining = True
+        self.layers = all_layers[:n_probe]
+        try:
+            run = lambda: self.forward(ids, pos, mask, sel, 0, n_splits=n_splits)
+            for name in self.LAYER_GEMMS:
+                inc = self.gemm_cfg[(name, mclass)]
+                graphs = []
+                for cand in self._step_candidates(name, mclass):
+                    self.gemm_cfg[(name, mclass)] = cand
+                    try:
+                        run()                                              # eager once: first-launch attributes, argument validation
+                        torch.cuda.synchronize()
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g):
+                            run()
+                    except cabi.LadeHipError:
+                        continue
+                    graphs.append((cand, g))
+                times = {c: float("inf") for c, _g in graphs}
+                for rnd in range(6):
+                    for cand, g in (graphs if rnd % 2 == 0 else graphs[::-1]):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        g.replay()
+                        e1.record()
+                        e1.synchronize()
+                        if rnd > 0:                                        # round 0 warms every graph up
+                            times[cand] = min(times[cand], e0.elapsed_time(e1) / n_probe)
+                best = min(times, key=times.get)
+                pick = best if times[best] < times.get(inc, float("inf")) * 0.997 else inc
+                self.gemm_cfg[(name, mclass)] = choice[name] = pick
+                log[name] = {"isolated_choice": inc, "in_step_choice": pick, "ms_per_layer_isolated_choice": round(times.get(inc, float("nan")), 5),
+                             "ms_per_layer_in_step_choice": round(times[pick], 5), "candidates": len(graphs)}
+                if os.environ.get("LADE_TUNE_VERBOSE"):
+                    top = " ".join(f"{c}:{t * 1e3:.1f}" for c, t in sorted(times.items(), key=lambda kv: kv[1])[:6])
+                    print(f"[tune-step] {name}:{mclass} rows={T} isolated choice {inc} {times.get(inc, float('nan')) * 1e3:.1f} us/layer -> {pick} "
+                          f"{times[pick] * 1e3:.1f} | {top}", file=sys.stderr, flush=True)
+                del graphs
+        finally:
+            self.layers = all_layers
+            self._refining = False
+            self.attn_events = saved_ev
+            for li, (k, v) in enumerate(kv_saved):
+                self._k_views[li][:, P:P + T].copy_(k)
+                self._vt_views[li][:, :, P:P + T].copy_(v)
+            torch.cuda.synchronize()
+        return choice, log
+
     LAYER_GEMMS = ("wqkv", "wo", "wgu", "wd")
     GEMM_NAMES = LAYER_GEMMS + ("lm_head",)
     ROW_CLASSES = (32, 64, 96, 128, 192, 256)
@@ -543,12 +673,17 @@ class StepEngine:
         the other ranks adopt its table through `adopt_gemm_cfg`, so that all replicas round alike)."""
         if not self.custom_gemm:
             return {}
-        return {f"{n}:{m}": self._tune(n, m) for n in self.GEMM_NAMES for m in self.ROW_CLASSES}
+        for m in self.ROW_CLASSES:
+            for n in self.GEMM_NAMES:
+                self._tune(n, m)
+            self._refine_in_step(m)
+        return {f"{n}:{m}": self.gemm_cfg[(n, m)] for n in self.GEMM_NAMES for m in self.ROW_CLASSES}
 
     def adopt_gemm_cfg(self, table: dict) -> None:
         for k, v in table.items():
             n, m = k.split(":")
             self.gemm_cfg[(n, int(m))] = None if v is None else (tuple(v) + (0,))[:6]       # (a 5-tuple of an older table: default ring)
+            self._refined.add(int(m))                # an adopted decision is final: every replica must run the kernels rank 0 chose
 
     # ---- one forward -----------------------------------------------------------------------------
     @_on_device
@@ -565,12 +700,17 @@ class StepEngine:
         qkv, o, gu, a = self.ws_qkv[:T], self.ws_o[:T], self.ws_gu[:T], self.ws_a[:T]
         if n_splits is None:
             n_splits = self.n_splits_for(T, P + T)
-        ops.gather_rows(self.embed, ids, out=x, rows=T)
         fused = self.custom_gemm and T <= self.ROW_CLASSES[-1]
         cfg_qkv = self._tune("wqkv", T) if fused else None
         cfg_o = self._tune("wo", T) if fused else None
         cfg_gu = self._tune("wgu", T) if fused else None
         cfg_d = self._tune("wd", T) if fused else None
+        if fused and not self._refining:
+            mclass = next(c for c in self.ROW_CLASSES if T <= c)
+            if mclass not in self._refined:          # once per row class: the four decisions re-taken INSIDE a step - BEFORE this call touches a workspace
+                self._refine_in_step(mclass)
+                cfg_qkv, cfg_o, cfg_gu, cfg_d = (self.gemm_cfg[(n, mclass)] for n in self.LAYER_GEMMS)
+        ops.gather_rows(self.embed, ids, out=x, rows=T)
         part = self.ws_part if fused else None
         r_parts = 0                     # > 0: the pending residual branch lives in `part` as that many split-K partials
         for li, lw in enumerate(self.layers):

@@ -238,23 +238,36 @@ def _oracle_margin(cfg, w_cpu_f32, dtype, tokens, n_prompt, tol, rel=0.0):
     return True, worst
 
 
-def _reference_bf16_envelope(cfg, w_cpu_f32, tokens, n_prompt):
+def _reference_bf16_envelope(cfg, w_cpu_f32, tokens, n_prompt, dtype=torch.bfloat16):
     """What the REFERENCE's own 16-bit arithmetic does to these logits: the oracle run twice over the same tokens on the same
     (bf16-rounded) weights - in fp32, and with every op output rounded to bf16 as the reference model computes in bf16
     (OracleLlama(dtype=bfloat16): torch's bf16 ops, fp32 accumulation inside a matmul, one rounding per op).  Returns the fp32 logits
     of the generated positions and the reference-bf16 error against them (rms, max).  This - not a number fitted to our own
-    measurements - is the error budget of the bf16 engine."""
-    wq = {k: v.to(torch.bfloat16).float() for k, v in w_cpu_f32.items()}
+    measurements - is the error budget of the bf16 engine.  dtype = torch.float16: the same in the reference's own
+    dtype (minimal.py:19, applications/eval_mtbench.py:116 load the model in fp16)."""
+    wq = {k: v.to(dtype).float() for k, v in w_cpu_f32.items()}
     T = len(tokens) - 1
     vis = np.tril(np.ones((T, T), dtype=bool))
     out = []
-    for dt in (torch.float32, torch.bfloat16):
+    for dt in (torch.float32, dtype):
         model = O.OracleLlama(cfg, wq, dtype=dt)
         hid = model.forward(tokens[:-1], list(range(T)), vis, model.new_cache())
         out.append(model.logits(hid[n_prompt - 1:]).float())
     z, z_ref = out
     e = z_ref - z
     return z, e.pow(2).mean().sqrt().item(), e.abs().max().item()
+
+
+def _record_envelope(tag, rms, mx, rms_ref, max_ref):
+    """the measured headroom against the reference's own 16-bit envelope, appended to gpurun_out/envelope_ratios.jsonl when that
+    directory exists (copied to profiles/ per round so the headroom is visible round over round)"""
+    import json
+    import os
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "envelope_ratios.jsonl"), "a") as f:
+            f.write(json.dumps({"case": str(tag), "engine_rms": round(rms, 5), "engine_max": round(mx, 5), "reference_rms": round(rms_ref, 5),
+                                "reference_max": round(max_ref, 5), "rms_ratio": round(rms / rms_ref, 3), "max_ratio": round(mx / max_ref, 3)}) + "\n")
 
 
 def _assert_engine_logits_within_reference_envelope(eng, z_fp32, rms_ref, max_ref, tokens, n_prompt, tag):
@@ -266,7 +279,9 @@ def _assert_engine_logits_within_reference_envelope(eng, z_fp32, rms_ref, max_re
     logits, _ = eng.prefill(tokens[:-1], list(range(n_prompt - 1, T)))
     e = logits.float().cpu() - z_fp32
     rms, mx = e.pow(2).mean().sqrt().item(), e.abs().max().item()
-    print(f"[{tag}] logit error vs fp32 oracle: engine rms {rms:.4f} max {mx:.4f} | reference-in-bf16 rms {rms_ref:.4f} max {max_ref:.4f}")
+    print(f"[{tag}] logit error vs fp32 oracle: engine rms {rms:.4f} max {mx:.4f} | reference-in-16-bit rms {rms_ref:.4f} max {max_ref:.4f} "
+          f"| ratios rms {rms / rms_ref:.3f} (bar 1.1) max {mx / max_ref:.3f} (bar 1.25)")
+    _record_envelope(tag, rms, mx, rms_ref, max_ref)
     assert rms <= 1.1 * rms_ref and mx <= 1.25 * max_ref, (tag, rms, rms_ref, mx, max_ref)
     return mx
 
@@ -293,9 +308,13 @@ def _assert_cache_equals_plain_prefill(eng, tokens, n_rows, tag):
 FULL_WIDTH = [("llama2-7b", 4, 15, 5, 15), ("codellama-13b", 3, 20, 7, 20), ("llama2-70b", 2, 15, 5, 15)]
 
 
+DTYPES = [torch.bfloat16, torch.float16]          # bf16 = BASELINE.json's config 2; f16 = the reference's own dtype (minimal.py:19)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "f16"])
 @pytest.mark.parametrize("shape,layers,W,N,G", FULL_WIDTH)
-def test_full_width_real_weights_bf16_cold(shape, layers, W, N, G):
-    """Untied random weights at the BASELINE widths (hidden / heads / GQA / vocab at full size, a few layers), bf16: attention,
+def test_full_width_real_weights_bf16_cold(shape, layers, W, N, G, dtype):
+    """Untied random weights at the BASELINE widths (hidden / heads / GQA / vocab at full size, a few layers), bf16 and f16: attention,
     GEMMs and glue all contribute to every logit.  The error budget is the REFERENCE's own: the oracle run in bf16 the way the
     reference model computes in bf16 (every op output rounded) deviates from its fp32 self by (rms_ref, max_ref) on these very
     tokens.  Required: (1) the engine's teacher-forced logits are at least as close to fp32 as that (rms <= 1.1 x, max <= 1.25 x);
@@ -306,30 +325,31 @@ def test_full_width_real_weights_bf16_cold(shape, layers, W, N, G):
     from lookaheaddecoding_amd.decoding import LookaheadDecoder
     from lookaheaddecoding_amd.engine import StepEngine
     cfg = make_config(shape, layers=layers)
-    w = random_weights_torch(cfg, seed=0, dtype=torch.bfloat16, device="cuda")
+    w = random_weights_torch(cfg, seed=0, dtype=dtype, device="cuda")
     w_cpu = {k: v.float().cpu() for k, v in w.items()}
-    eng = StepEngine(cfg, w, dtype=torch.bfloat16, device="cuda", max_seq=1024, max_T=512)
+    eng = StepEngine(cfg, w, dtype=dtype, device="cuda", max_seq=1024, max_T=512)
     del w
     prompt = torch.randint(3, cfg["vocab"], (96,), generator=torch.Generator().manual_seed(123)).tolist()
     n_new = 24
     plain = eng.plain_greedy(prompt, len(prompt) + n_new)
-    z, rms_ref, max_ref = _reference_bf16_envelope(cfg, w_cpu, plain, len(prompt))
-    _assert_engine_logits_within_reference_envelope(eng, z, rms_ref, max_ref, plain, len(prompt), shape)
+    z, rms_ref, max_ref = _reference_bf16_envelope(cfg, w_cpu, plain, len(prompt), dtype)
+    _assert_engine_logits_within_reference_envelope(eng, z, rms_ref, max_ref, plain, len(prompt), f"{shape} {str(dtype)[6:]}")
     TOL = 2.5 * max_ref
-    ok, worst_plain = _oracle_margin(cfg, w_cpu, torch.bfloat16, plain, len(prompt), tol=TOL)
+    ok, worst_plain = _oracle_margin(cfg, w_cpu, dtype, plain, len(prompt), tol=TOL)
     assert ok, ("plain", shape, worst_plain, TOL)
     for use_graph in (False, True):
         dec = LookaheadDecoder(eng, W, N, G, use_graph=use_graph)
         out = dec.greedy(prompt, len(prompt) + n_new, rng=random.Random(1))
         if out.tokens != plain:
-            ok, worst = _oracle_margin(cfg, w_cpu, torch.bfloat16, out.tokens, len(prompt), tol=TOL)
+            ok, worst = _oracle_margin(cfg, w_cpu, dtype, out.tokens, len(prompt), tol=TOL)
             assert ok, (shape, use_graph, worst, TOL)
         _assert_cache_equals_plain_prefill(eng, dec.tokens, dec.P, (shape, use_graph))
     print(f"[{shape}] worst margin deficit of the plain stream {worst_plain:.4f} (allowed 2.5 x the reference's own bf16 error {max_ref:.4f} = {TOL:.4f})")
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "f16"])
 @pytest.mark.parametrize("shape,layers,W,N,G", FULL_WIDTH)
-def test_full_width_real_weights_bf16_with_accepted_ngrams(shape, layers, W, N, G):
+def test_full_width_real_weights_bf16_with_accepted_ngrams(shape, layers, W, N, G, dtype):
     """The accept path with live attention / MLP at the BASELINE widths: tied embeddings of larger scale (std 1.0, the same
     order as a layer's contribution to the residual stream) make the model copy-biased, so its greedy stream becomes
     periodic and the pool hits (S > 2), while every projection still feeds the residual stream.  Lookahead == plain greedy on the same engine, every token within the oracle margin, and the cache
@@ -337,21 +357,21 @@ def test_full_width_real_weights_bf16_with_accepted_ngrams(shape, layers, W, N, 
     from lookaheaddecoding_amd.decoding import LookaheadDecoder
     from lookaheaddecoding_amd.engine import StepEngine
     cfg = make_config(shape, layers=layers)
-    w = random_weights_torch(cfg, seed=0, dtype=torch.bfloat16, device="cuda")
-    w["embed"] = (w["embed"].float() * (1.0 / 0.02)).bfloat16()
+    w = random_weights_torch(cfg, seed=0, dtype=dtype, device="cuda")
+    w["embed"] = (w["embed"].float() * (1.0 / 0.02)).to(dtype)
     w["lm_head"] = w["embed"]
     w_cpu = {k: v.float().cpu() for k, v in w.items()}
-    eng = StepEngine(cfg, w, dtype=torch.bfloat16, device="cuda", max_seq=1024, max_T=512)
+    eng = StepEngine(cfg, w, dtype=dtype, device="cuda", max_seq=1024, max_T=512)
     del w
     prompt = [(7 * i) % 50 + 3 for i in range(96)]
     n_new = 48
     plain = eng.plain_greedy(prompt, len(prompt) + n_new)
-    assert _oracle_margin(cfg, w_cpu, torch.bfloat16, plain, len(prompt), tol=0.06, rel=0.01)[0]
+    assert _oracle_margin(cfg, w_cpu, dtype, plain, len(prompt), tol=0.06, rel=0.01)[0]
     for use_graph in (False, True):
         dec = LookaheadDecoder(eng, W, N, G, pool_from_prompt=True, use_graph=use_graph)
         out = dec.greedy(prompt, len(prompt) + n_new, rng=random.Random(1), keep_trace=True)
         if out.tokens != plain:
-            assert _oracle_margin(cfg, w_cpu, torch.bfloat16, out.tokens, len(prompt), tol=0.06, rel=0.01)[0], (shape, use_graph)
+            assert _oracle_margin(cfg, w_cpu, dtype, out.tokens, len(prompt), tol=0.06, rel=0.01)[0], (shape, use_graph)
         assert out.steps * 2 < out.generated, (shape, use_graph, out.steps)                  # S > 2: n-grams are accepted
         assert max(t["max_hit"] for t in out.trace) == N - 2
         _assert_cache_equals_plain_prefill(eng, dec.tokens, dec.P, (shape, use_graph))
