@@ -8,6 +8,7 @@ Metric (BASELINE.json): tokens/s + step-compression of lookahead decoding on a s
     c3            same model, sampling (temperature 0.8), device-side verify
     c4            CodeLlama-13B shape (40 L), greedy, W=20 N=7 G=20 (steps of 120..240 tokens)
     c5            Llama-2-70B shape (80 L, GQA 64/8), greedy, lookahead-parallel code path (one rank with --gpus 1)
+    lp7b / lp70b  (not BASELINE configurations) the reference's default W=60 N=8 G=60 on the lookahead-parallel path: the regime LP is built for
 
 A "step" is one decode step of the lookahead loop = one model forward over T=(N-1)(W+g) tokens through the HIP hot path (input
 assembly, RoPE+KV append, lookahead attention, argmax / probability table, verify, pool insert, window roll, KV commit) with the
@@ -46,6 +47,10 @@ CONFIGS = {
     "c3": dict(model="llama2-7b", W=15, N=5, G=15, mode="sample", temperature=0.8, what="BASELINE config 3: Llama-2-7B-chat shape, sampling temperature 0.8"),
     "c4": dict(model="codellama-13b", W=20, N=7, G=20, mode="greedy", what="BASELINE config 4: CodeLlama-13B shape, W=20 N=7 G=20 (long-guess verify branch)"),
     "c5": dict(model="llama2-70b", W=15, N=5, G=15, mode="greedy", lp=True, what="BASELINE config 5: Llama-2-70B shape (GQA 64/8), lookahead-parallel path"),
+    # not BASELINE configurations: the reference's DEFAULT lookahead configuration (lade/decoding.py:854-862: W = 60, N = 8, G = 60 - 420..840 rows
+    # per step on one rank, 100..130 per rank at 8), the regime lookahead parallelism is built for (tools/lp_curve.py)
+    "lp7b": dict(model="llama2-7b", W=60, N=8, G=60, mode="greedy", lp=True, what="reference default W=60 N=8 G=60, Llama-2-7B shape, lookahead-parallel path"),
+    "lp70b": dict(model="llama2-70b", W=60, N=8, G=60, mode="greedy", lp=True, what="reference default W=60 N=8 G=60, Llama-2-70B shape, lookahead-parallel path"),
 }
 
 
@@ -499,6 +504,55 @@ def worker(args):
         eng.embed.mul_(1.0 / applied)
         return out_l
 
+    # ---- the regime the reference publishes (S ~ 1.6-2.3 on real checkpoints, 1.5-2.3 x over autoregressive decoding): the same
+    # live-weights construction as hot_live, with the embedding scale searched for the acceptance rate instead of taken at saturation -
+    # a weakly copy-biased model accepts an n-gram now and then, so steps carry candidates (T > 60) and only some of them pay off
+    def mid_regime(plain_ms):
+        live_prompt = [(7 * i) % 50 + 3 for i in range(args.prompt_len)]
+        saved_head, saved_embed = eng.lm_head, eng.embed.clone()
+        lo, hi = 1.6, 2.3
+
+        def trial(scale, n_steps):
+            eng.embed.copy_(saved_embed)
+            eng.embed.mul_(scale)
+            eng.lm_head = eng.embed
+            ld = LookaheadDecoder(eng, W, N, G, pool_from_prompt=True, use_graph=not args.no_graph)
+            ld.start(live_prompt, rng=random.Random(1))
+            for _ in range(N - 1 + args.warmup):
+                ld.step()
+            sync()
+            t0_tok, t0 = len(ld.tokens), time.perf_counter()
+            infos_ = [ld.step() for _ in range(n_steps)]
+            sync()
+            return ld, (len(ld.tokens) - t0_tok) / n_steps, time.perf_counter() - t0, infos_
+
+        tried, best = [], None
+        for scale in (24.0, 32.0, 40.0, 48.0, 56.0, 64.0, 80.0, 96.0, 128.0, 192.0, 256.0):
+            _ld, S_t, _t, _i = trial(scale, 16)
+            tried.append([scale, round(S_t, 2)])
+            d = 0.0 if lo <= S_t <= hi else min(abs(S_t - lo), abs(S_t - hi))
+            if best is None or d < best[0]:
+                best = (d, scale)
+            if d == 0.0 or S_t > hi:
+                break
+        scale = best[1]
+        ld, S_m, tl, li = trial(scale, args.steps)
+        gen_all = ld.tokens[len(live_prompt):]
+        n_chk = min(len(gen_all), 64)
+        plain_ref = eng.plain_greedy(live_prompt, len(live_prompt) + n_chk)[len(live_prompt):]
+        n_same = next((i for i, (x, y) in enumerate(zip(gen_all, plain_ref)) if x != y), n_chk)
+        step_ms = tl / args.steps * 1e3
+        out_m = {"value": round(S_m * args.steps / tl, 2), "unit": "tokens/s", "step_compression": round(S_m, 3), "ms_per_step": round(step_ms, 3),
+                 "tokens_per_step_T": round(sum(i["T"] for i in li) / len(li), 1), "embedding_scale": scale, "scales_tried_S": tried,
+                 "in_published_range": bool(lo <= S_m <= hi),
+                 "plain_ms_per_token": plain_ms, "speedup_vs_plain": None if not plain_ms else round(S_m * plain_ms / step_ms, 3),
+                 "equals_plain_greedy_for": f"{n_same} of the first {n_chk} generated tokens",
+                 "how": "live weights, embedding scale searched (tied to lm_head, periodic prompt, POOL_FROM_PROMPT=1) for a step compression inside the range "
+                        "BASELINE.md quotes for real checkpoints (1.6-2.3); speedup_vs_plain = S x plain one-token step / lookahead step on the same engine"}
+        eng.lm_head = saved_head
+        eng.embed.copy_(saved_embed)
+        return out_m
+
     def hot_regime():
         Cy = 256
         eng.zero_projections(("wo", "wd"))
@@ -567,6 +621,7 @@ def worker(args):
                             "stream in 4 eager steady steps after the timed region, every layer, minus what an empty bracket - two events recorded back to back "
                             "in the same place - reads (launch_us_in_step.empty_bracket_us; used when those steps are GPU bound); else isolated "
                             "back-to-back launches cycling through the layers' K/V caches (every launch reads HBM)"}
+        mid = mid_regime(plain["ms_per_token"] if plain else None) if extras else None
         hot_l = hot_live() if extras else None
         hot = hot_regime() if extras else None          # last: it zeroes o_proj / down_proj
         cpu = None
@@ -595,7 +650,7 @@ def worker(args):
             "prefill": {"tokens": args.prompt_len + W + N - 3, "ms": round(prefill_s * 1e3, 2), "tokens_per_s": round((args.prompt_len + W + N - 3) / prefill_s, 1),
                         "how": f"prompt + first window level as causal chunks of <= {args.chunk} rows through the same attention / GEMM kernels, lm_head on the "
                                "rows that are read only; second prefill of the process (the first one pays the one-off GEMM autotune)"},
-            "hot_regime": hot_l, "hot_regime_forced": hot, "plain_decode": plain, "roofline": roofline,
+            "mid_regime": mid, "hot_regime": hot_l, "hot_regime_forced": hot, "plain_decode": plain, "roofline": roofline,
             # the whole step against the same HBM peak: the bytes a step cannot avoid reading (weights + K/V cache + lm_head) / its time
             "step_stream": {"bound": "hbm", "bytes_per_step": step_stream_bytes(cfg, P_end, 1), "achieved": round(step_stream_bytes(cfg, P_end, 1) / (elapsed / args.steps) / 1e9, 1),
                             "peak": 8000.0, "unit": "GB/s", "frac": round(step_stream_bytes(cfg, P_end, 1) / (elapsed / args.steps) / 1e9 / 8000.0, 4),

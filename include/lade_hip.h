@@ -76,17 +76,9 @@ extern "C" {
 #define LADE_MAX_GUESS_SET 64    /* G  (candidates per key; one wave lane per slot) */
 #define LADE_REC_WORDS (8 + LADE_MAX_LEVEL)      /* int32 words of a step's record */
 /* Seal of a step record (its last word), so that a host polling a pinned copy can tell a complete record of step `step_no` from a stale
- * or half-landed one: a multiplicative hash of the step number xor-folded with the other words, each times an odd constant. */
-#if defined(__HIPCC__)
-#define LADE_HOST_DEVICE __host__ __device__
-#else
-#define LADE_HOST_DEVICE
-#endif
-static inline LADE_HOST_DEVICE uint32_t lade_record_seal(const uint32_t* rec, uint32_t step_no) {
-    uint32_t x = step_no * 0x9E3779B1u + 0x7F4A7C15u;
-    for (uint32_t w = 0; w + 1 < LADE_REC_WORDS; ++w) x ^= (rec[w] + w) * (2u * w + 0x85EBCA6Bu);
-    return x;
-}
+ * or half-landed one: a multiplicative hash of the step number xor-folded with the other words, each times an odd constant (the
+ * definition is seal_words() in csrc/common.hpp, shared by the kernel and this host entry point).  rec: LADE_REC_WORDS words in HOST memory. */
+uint32_t lade_record_seal(const uint32_t* rec, uint32_t step_no);
 
 /* ---- control block ------------------------------------------------------------------
  * One int32 array in HBM carries the dynamic state of a sequence between kernels, so a steady
@@ -366,6 +358,15 @@ int lade_rope_kv_append_parts(const float* parts, int32_t n_parts, int64_t part_
                               int32_t dtype, void* stream);
 int lade_splitk_reduce(const float* part, void* C, int64_t ldc, int32_t M, int32_t N, int32_t n_split, int32_t dtype,
                        void* stream);
+
+/* ---- experiment: weight stream read ahead into the Infinity Cache from a second stream (csrc/prefetch.hip) ----
+ * lade_gemm_progress_counter: the device int32 the skinny GEMM launches bump once each (null = off; process-wide).
+ * lade_stream_prefetch: n_wgs work-groups read the segments {ptr, bytes, cum} (uint64 x 3 each, device memory, in the order the step's
+ * GEMMs consume them), at most lead_bytes ahead of the segment the counter says is being consumed; every wait is bounded by spin_cap.
+ * policy 1 = non-temporal loads. */
+int lade_gemm_progress_counter(int32_t* counter, void* stream);
+int lade_stream_prefetch(const void* segs, int32_t n_seg, int32_t* progress, int64_t lead_bytes, int32_t spin_cap, int32_t policy,
+                         int32_t n_wgs, void* stream);
 
 /* ---- misc ------------------------------------------------------------------------------- */
 int lade_version(void);

@@ -29,12 +29,9 @@ REC_WORDS = 8 + MAX_LEVEL
 
 
 def record_seal(rec, step_no: int) -> int:
-    """lade_record_seal of include/lade_hip.h on the host: the last word of a step record as the device computes it (32-bit wrap-around)"""
-    M = 0xFFFFFFFF
-    x = ((step_no & M) * 0x9E3779B1 + 0x7F4A7C15) & M
-    for w in range(REC_WORDS - 1):
-        x ^= ((((rec[w] & M) + w) & M) * ((2 * w + 0x85EBCA6B) & M)) & M
-    return x
+    """lade_record_seal over a snapshot of a step record (list / array of REC_WORDS int32): what its last word must be"""
+    arr = (C.c_uint32 * REC_WORDS)(*[int(x) & 0xFFFFFFFF for x in rec])
+    return int(lib().lade_record_seal(arr, int(step_no) & 0xFFFFFFFF))
 
 
 class LadeHipError(RuntimeError):
@@ -100,6 +97,9 @@ SIGNATURES = {
     "lade_silu_mul_parts": [_vp, _i32, _i64, _vp, _i32, _i32, _i32, _i32, _vp],
     "lade_rope_kv_append_parts": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "lade_splitk_reduce": [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
+    "lade_record_seal": [C.POINTER(C.c_uint32), C.c_uint32],
+    "lade_gemm_progress_counter": [_vp, _vp],
+    "lade_stream_prefetch": [_vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp],
     "lade_version": [],
     "lade_last_error_string": [],
     "lade_time_attn": [C.POINTER(AttnArgs), _i32, C.POINTER(C.c_float), _vp],
@@ -125,7 +125,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         except AttributeError as e:
             raise LadeHipError(f"{path} does not export {name}") from e
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name == "lade_last_error_string" else C.c_int
+        fn.restype = C.c_char_p if name == "lade_last_error_string" else (C.c_uint32 if name == "lade_record_seal" else C.c_int)
     _lib = lib
     return lib
 

@@ -22,6 +22,13 @@ int check_launch(const char* what);
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// seal of a step record (include/lade_hip.h: lade_record_seal): one definition for the kernel that writes it and the host that checks it
+__host__ __device__ static inline uint32_t seal_words(const uint32_t* rec, uint32_t step_no) {
+    uint32_t x = step_no * 0x9E3779B1u + 0x7F4A7C15u;
+    for (uint32_t w = 0; w + 1 < LADE_REC_WORDS; ++w) x ^= (rec[w] + w) * (2u * w + 0x85EBCA6Bu);
+    return x;
+}
+
 // ---- device: 16-bit float storage <-> fp32 ---------------------------------------------
 struct BF16 {};  // tag types: storage is uint16_t
 struct F16 {};

@@ -572,7 +572,7 @@ __global__ __launch_bounds__(64) void greedy_post_step_kernel(int32_t* ctl, int3
     __syncthreads();
     // the record's last word seals it: a host that POLLS its pinned copy (no stream synchronisation: the copy lands word by word) accepts
     // the record only when the seal matches the step number it waits for and the other 23 words it has read
-    if (lane == 0) rec_s[LADE_REC_WORDS - 1] = (int32_t)lade_record_seal((const uint32_t*)rec_s, (uint32_t)step_no);
+    if (lane == 0) rec_s[LADE_REC_WORDS - 1] = (int32_t)seal_words((const uint32_t*)rec_s, (uint32_t)step_no);
     __syncthreads();
     if (lane < LADE_REC_WORDS) {
         record[lane] = rec_s[lane];
@@ -782,6 +782,8 @@ extern "C" int lade_argmax_rows(const void* logits, int64_t ld, int32_t rows, in
     }
     return check_launch("lade_argmax_rows");
 }
+
+extern "C" uint32_t lade_record_seal(const uint32_t* rec, uint32_t step_no) { return rec ? seal_words(rec, step_no) : 0u; }
 
 extern "C" int lade_greedy_post_step(int32_t* ctl, int32_t* window, int32_t wcap, int32_t* pool_tok, int32_t* pool_cnt, int32_t V,
                                      int32_t W, int32_t N, int32_t G, const int32_t* am, int32_t n_inp, int32_t* guess, int32_t T_step,

@@ -18,7 +18,7 @@ import torch
 
 from . import cabi, ops
 from .cabi import (CTL_FILL_LEVEL, CTL_G, CTL_HITS, CTL_LST_POS, CTL_LST_TOKEN, CTL_N_INPUT, CTL_P, CTL_WLEN, CTL_WORDS,
-                   REC_WORDS, call, ptr)
+                   REC_WORDS, call, ptr, record_seal)
 from .engine import StepEngine, _on_device
 from .ops import StepMask
 
@@ -60,6 +60,7 @@ class LadeState:
         self.am = torch.zeros(1 + self.wcap + G * self.gs, **i32)
         self.record = torch.zeros(REC_WORDS, **i32)
         self.record_host = torch.zeros(REC_WORDS, dtype=torch.int32).pin_memory()
+        self.record_host_np = self.record_host.numpy()          # the same pinned bytes, for the polling read (poll_record)
         self.device = device
 
     def reset(self, window0: Sequence[int], n_prompt: int, prompt_tail: Sequence[int]) -> None:
@@ -80,6 +81,19 @@ class LadeState:
         torch.cuda.current_stream().synchronize()
         return self.record_host.tolist()
 
+    def poll_record(self, step_no: int, spin_limit: int = 2_000_000) -> Optional[List[int]]:
+        """The record of step `step_no` as `lade_greedy_post_step` stored it into the pinned host buffer (mapped into the device: no
+        copy node, no stream synchronisation).  The host spins on the buffer until the record carries that step number and its seal
+        (`lade_record_seal` over the other words) matches what was read - a stale or half-landed record fails one of the two.
+        None when the record does not arrive within the spin limit (the caller then synchronises the stream and reads it the slow way)."""
+        buf = self.record_host_np
+        for _ in range(spin_limit):
+            if buf[7] == step_no:
+                rec = buf.tolist()
+                if rec[7] == step_no and (rec[REC_WORDS - 1] & 0xFFFFFFFF) == record_seal(rec, step_no):
+                    return rec
+        return None
+
 
 class LookaheadDecoder:
     """Greedy / sampling lookahead decoding of one sequence on a `StepEngine`."""
@@ -95,6 +109,8 @@ class LookaheadDecoder:
         self.W, self.N, self.G, self.gs = W, N, G, N - 1
         self.pool_from_prompt = bool(pool_from_prompt)
         self.lp = lp                      # lookahead-parallel context (parallel.LPContext) or None
+        self.poll = os.environ.get("LADE_POLL", "1") != "0"       # steady hipGraph steps: poll the host-mapped record instead of synchronising
+        self._step_no = 0                 # device step counter (ctl[STEP]) as of the last record read
         self.device = engine.device
         self.st = LadeState(engine.V, W, N, G, engine.device, engine.max_T)
         if self.max_step_tokens() > engine.max_T:
@@ -145,6 +161,7 @@ class LookaheadDecoder:
         self.eos = -1 if eos_token_id is None else int(eos_token_id)
         self.tokens = list(self.prompt)
         self.steps, self.P, self.g, self.fill_level = 0, 0, 0, 0
+        self._step_no = 0                  # st.reset zeroed ctl[STEP]
         self.finished_by_eos = False
 
     # ---- steady step as ONE hipGraph ------------------------------------------------------------------
@@ -177,10 +194,14 @@ class LookaheadDecoder:
         ops.argmax_rows(logits, out=st.am)
         if forward_only:
             return logits.float()                                   # logits.float(), modeling_llama.py:1544
+        # LADE_POLL (default on): the post-step stores the sealed record straight into the pinned host buffer and the host polls for it;
+        # otherwise a copy node carries it and the host synchronises the stream
         call("lade_greedy_post_step", ptr(st.ctl), ptr(st.window), st.wcap, ptr(st.pool_tok), ptr(st.pool_cnt), st.V, W, N, G,
-             ptr(st.am), W, ptr(st.guess), T, cand_rows, 2, int(self.pool_from_prompt), ptr(st.tail), self.eos, None, None, ptr(st.record))
+             ptr(st.am), W, ptr(st.guess), T, cand_rows, 2, int(self.pool_from_prompt), ptr(st.tail), self.eos, None, None, ptr(st.record),
+             ptr(st.record_host) if self.poll else None)
         ops.kv_commit(e.kv, 0, 0, 0, ctl=st.ctl)
-        st.record_host.copy_(st.record, non_blocking=True)
+        if not self.poll:
+            st.record_host.copy_(st.record, non_blocking=True)
 
     def _capture_graphs(self, forward_only: bool = False) -> None:
         e, st = self.e, self.st
@@ -213,6 +234,8 @@ class LookaheadDecoder:
             with torch.cuda.graph(g):
                 self._graph_logits[gcap] = self._graph_body(gcap, forward_only)
             self._graphs[gcap] = g
+        torch.cuda.synchronize()
+        st.record_host.zero_()              # the warm-up passes left records of the step number the first replay will produce: never mistake one for it
         self._graph = "forward" if forward_only else "step"
         self._graph_eos = self.eos
         self._graph_gen = e.generation
@@ -229,8 +252,14 @@ class LookaheadDecoder:
             raise cabi.LadeHipError(f"KV cache exhausted: P={self.P} + T={T} > S_max={e.S_max}")
         P_before = self.P
         self._graphs[gcap].replay()
-        torch.cuda.current_stream().synchronize()
-        rec = st.record_host.tolist()
+        rec = st.poll_record(self._step_no + 1) if self.poll else None
+        if rec is None:
+            torch.cuda.current_stream().synchronize()
+            if self.poll:                          # the record never arrived through the mapped buffer: read the device copy
+                rec = st.read_record()
+            else:
+                rec = st.record_host.tolist()
+        self._step_no = rec[7]
         self.steps += 1
         max_hit, n_accept, eos_hit, self.g, self.P = rec[0], rec[1], rec[2], rec[3], rec[4]
         accepted = rec[8:8 + n_accept]
@@ -273,9 +302,10 @@ class LookaheadDecoder:
             logits = e.forward(st.ids, st.pos, mask, st.sel, n_sel)
         ops.argmax_rows(logits, out=st.am)
         call("lade_greedy_post_step", ptr(st.ctl), ptr(st.window), st.wcap, ptr(st.pool_tok), ptr(st.pool_cnt), st.V, W, N, G,
-             ptr(st.am), n_inp, ptr(st.guess), T, cand_rows, phase, int(self.pool_from_prompt), ptr(st.tail), self.eos, None, None, ptr(st.record))
+             ptr(st.am), n_inp, ptr(st.guess), T, cand_rows, phase, int(self.pool_from_prompt), ptr(st.tail), self.eos, None, None, ptr(st.record), None)
         ops.kv_commit(e.kv, 0, 0, 0, ctl=st.ctl)
         rec = st.read_record()
+        self._step_no = rec[7]
         self.steps += 1
         max_hit, n_accept, eos_hit, self.g, self.P = rec[0], rec[1], rec[2], rec[3], rec[4]
         accepted = rec[8:8 + n_accept]
@@ -479,9 +509,10 @@ class LookaheadDecoder:
             forced[2 + max_hit:3 + max_hit].copy_(drawn_on_device)          # the drawn token never left the device
         call("lade_greedy_post_step", ptr(st.ctl), ptr(st.window), st.wcap, ptr(st.pool_tok), ptr(st.pool_cnt), st.V, W, N, G,
              ptr(st.am), n_inp, ptr(st.guess), T, cand_rows, phase, int(self.pool_from_prompt), ptr(st.tail), self.eos,
-             ptr(forced), ptr(level_override), ptr(st.record))
+             ptr(forced), ptr(level_override), ptr(st.record), None)
         ops.kv_commit(e.kv, 0, 0, 0, ctl=st.ctl)
         rec = st.read_record()
+        self._step_no = rec[7]
         self.steps += 1
         n_accept, eos_hit, self.g, self.P = rec[1], rec[2], rec[3], rec[4]
         accepted = rec[8:8 + n_accept]                                     # = hits[:n_accept]; the record also carries a device-drawn token
