@@ -359,15 +359,6 @@ int lade_rope_kv_append_parts(const float* parts, int32_t n_parts, int64_t part_
 int lade_splitk_reduce(const float* part, void* C, int64_t ldc, int32_t M, int32_t N, int32_t n_split, int32_t dtype,
                        void* stream);
 
-/* ---- experiment: weight stream read ahead into the Infinity Cache from a second stream (csrc/prefetch.hip) ----
- * lade_gemm_progress_counter: the device int32 the skinny GEMM launches bump once each (null = off; process-wide).
- * lade_stream_prefetch: n_wgs work-groups read the segments {ptr, bytes, cum} (uint64 x 3 each, device memory, in the order the step's
- * GEMMs consume them), at most lead_bytes ahead of the segment the counter says is being consumed; every wait is bounded by spin_cap.
- * policy 1 = non-temporal loads. */
-int lade_gemm_progress_counter(int32_t* counter, void* stream);
-int lade_stream_prefetch(const void* segs, int32_t n_seg, int32_t* progress, int64_t lead_bytes, int32_t spin_cap, int32_t policy,
-                         int32_t n_wgs, void* stream);
-
 /* ---- misc ------------------------------------------------------------------------------- */
 int lade_version(void);
 const char* lade_last_error_string(void);

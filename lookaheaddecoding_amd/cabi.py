@@ -98,8 +98,6 @@ SIGNATURES = {
     "lade_rope_kv_append_parts": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "lade_splitk_reduce": [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
     "lade_record_seal": [C.POINTER(C.c_uint32), C.c_uint32],
-    "lade_gemm_progress_counter": [_vp, _vp],
-    "lade_stream_prefetch": [_vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp],
     "lade_version": [],
     "lade_last_error_string": [],
     "lade_time_attn": [C.POINTER(AttnArgs), _i32, C.POINTER(C.c_float), _vp],

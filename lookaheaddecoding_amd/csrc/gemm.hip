@@ -94,7 +94,6 @@ static int gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, b
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("LADE_GEMM_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
     g.epi = epilogue;
     g.n_stage = ring;
-    g.progress = g_progress;
     hipStream_t st = (hipStream_t)stream;
     const int rc = dtype == LADE_BF16 ? gemm_dispatch_bf16(g, st, mw, mt, ng, nt) : gemm_dispatch_f16(g, st, mw, mt, ng, nt);
     if (rc >= 0) return rc;

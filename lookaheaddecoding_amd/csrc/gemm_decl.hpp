@@ -18,14 +18,11 @@ struct GemmK {
     int64_t w_ts;          // 0: W is row-major [N][ldw];  64 N: W is K-tile-major [K/64][N][64] (elements between the K tiles of a row)
     int M, N, K, n_split;
     int n_stage;           // LDS ring depth of this launch (0: the shape's default)
-    int32_t* progress;     // experiment (prefetch.hip): bumped once per launch; null = off
     int dbg;               // ablation switches for tools/gemm_ablate.py (LADE_GEMM_DBG): 1 = no output stores, 4 = no LDS reads / MFMA
     int epi;               // n_split == 1 only: 0 = C = A.W^T;  1 = SwiGLU over interleaved gate / up rows, C is [M][N/2]
 };
 
 // launch the kernel built for this wave grid (mw x ng waves compute, mt x nt MFMA tiles each); -1 when it is not in the shape table
-extern int32_t* g_progress;        // prefetch.hip
-
 int gemm_dispatch_bf16(const GemmK& g, hipStream_t st, int mw, int mt, int ng, int nt);
 int gemm_dispatch_f16(const GemmK& g, hipStream_t st, int mw, int mt, int ng, int nt);
 

@@ -87,8 +87,6 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
     const int ql = lane & 31, hi = lane >> 5;
     const int n0 = blockIdx.x * BN, split = blockIdx.y, m0 = blockIdx.z * BM;
 
-    if (g.progress && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && tid == 0) atomicAdd(g.progress, 1);      // prefetch.hip pacing
-
     const int k_tiles = (g.K + G_BK - 1) / G_BK;
     const int tps = (k_tiles + g.n_split - 1) / g.n_split;
     const int t0 = split * tps;

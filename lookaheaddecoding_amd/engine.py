@@ -158,9 +158,6 @@ class StepEngine:
         self._refined = set()               # row classes whose decisions were re-taken inside the step (_refine_in_step)
         self._refining = False
         self.step_tune_log = {}             # row class -> what the in-step pass measured (bench.py prints it)
-        # experiment (csrc/prefetch.hip): LADE_PREFETCH=<work-groups> reads the step's weight stream ahead into the Infinity Cache from a second stream
-        self._pf_wgs = int(os.environ.get("LADE_PREFETCH", "0"))
-        self._pf = None
         self._alloc_workspaces(max_T)
         try:
             self.n_cu = torch.cuda.get_device_properties(self.device.index).multi_processor_count
@@ -688,42 +685,9 @@ class StepEngine:
             self.gemm_cfg[(n, int(m))] = None if v is None else (tuple(v) + (0,))[:6]       # (a 5-tuple of an older table: default ring)
             self._refined.add(int(m))                # an adopted decision is final: every replica must run the kernels rank 0 chose
 
-    def _prefetch_setup(self):
-        if self._pf is None:
-            segs, cum = [], 0
-            for lw in self.layers:
-                for n in self.LAYER_GEMMS:
-                    w = self._w(lw, n)
-                    b = w.numel() * w.element_size()
-                    segs += [w.data_ptr(), b, cum]
-                    cum += b
-            lm = self._lm_kt if self._lm_kt is not None else self._lm_head
-            segs += [lm.data_ptr(), lm.numel() * lm.element_size(), cum]
-            self._pf = dict(segs=torch.tensor(segs, dtype=torch.int64).to(self.device), n=len(segs) // 3,
-                            progress=torch.zeros(2, dtype=torch.int32, device=self.device), stream=torch.cuda.Stream(device=self.device),
-                            lead=int(float(os.environ.get("LADE_PREFETCH_LEAD_MB", "128")) * (1 << 20)),
-                            policy=int(os.environ.get("LADE_PREFETCH_NT", "0")), spin=int(os.environ.get("LADE_PREFETCH_SPIN", "2000")))
-            cabi.call("lade_gemm_progress_counter", cabi.ptr(self._pf["progress"]))
-        return self._pf
-
     # ---- one forward -----------------------------------------------------------------------------
     @_on_device
-    def forward(self, *a, **k):
-        pf = None
-        if self._pf_wgs > 0 and self.custom_gemm and len(self.layers) == self.L:      # (not during the in-step tuning probe: its layer list is a slice)
-            pf = self._prefetch_setup()
-            pf["progress"].zero_()
-            cur = torch.cuda.current_stream()
-            pf["stream"].wait_stream(cur)
-            with torch.cuda.stream(pf["stream"]):
-                cabi.call("lade_stream_prefetch", cabi.ptr(pf["segs"]), pf["n"], cabi.ptr(pf["progress"]), pf["lead"], pf["spin"], pf["policy"], self._pf_wgs)
-        try:
-            return self._forward(*a, **k)
-        finally:
-            if pf is not None:
-                torch.cuda.current_stream().wait_stream(pf["stream"])
-
-    def _forward(self, ids: torch.Tensor, pos: torch.Tensor, mask: StepMask, sel_rows: torch.Tensor, n_sel: int,
+    def forward(self, ids: torch.Tensor, pos: torch.Tensor, mask: StepMask, sel_rows: torch.Tensor, n_sel: int,
                 dyn_P: Optional[torch.Tensor] = None, n_splits: Optional[int] = None) -> torch.Tensor:
         """ids/pos: device int32 [>=T]; mask describes the step; sel_rows: device int32 [n_sel] rows whose
         logits are needed.  Appends the T new K/V rows at P..P+T and returns logits [n_sel, V] (model dtype,

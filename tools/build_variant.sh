@@ -7,7 +7,7 @@ NAME=$1; shift
 EXTRA="$*"
 mkdir -p build_$NAME
 OBJS=""
-for f in attn.hip kv.hip intops.hip glue.hip sampling.hip prefetch.hip gemm.hip gemm_bf16.hip gemm_f16.hip cabi.cpp lpcomm.cpp; do
+for f in attn.hip kv.hip intops.hip glue.hip sampling.hip gemm.hip gemm_bf16.hip gemm_f16.hip cabi.cpp lpcomm.cpp; do
     o=build_$NAME/${f%.*}.o
     x=""; [ "${f##*.}" = "cpp" ] && x="-x hip"
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable $EXTRA $x -c $f -o $o &
