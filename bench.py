@@ -202,7 +202,22 @@ def cpu_baseline(c, cfg_full, prompt_len, n_steps, allow_full=True):
                   f"{fixed * 1e3:.0f} ms of lm_head / embedding) scaled to {cfg_full['layers']} layers = {step_s:.2f} s/step (full depth, {n_param * 4 / 1e9:.0f} GB in fp32, "
                   f"is beyond the bench's memory / time budget), KV cache of {prompt_len} synthetic rows, steady steps of T={T} tokens, W={W} N={N} G={G}, "
                   f"S=1.0 (cold regime: 1 token/step)")
-    return {"value": round(1.0 / step_s, 4), "unit": "tokens/s", "cores": cores, "kind": "port", "sample": sample, "s_per_step": round(step_s, 4)}
+    # what the port's speed is worth as the reference's: oracle/cpu_calibration.json (written by oracle/calibrate_cpu_baseline.py in the build
+    # container, where the unmodified reference runs through the shim) holds both timed on the same models, prompt, window RNG and cores
+    calib = None
+    try:
+        with open(os.path.join(ROOT, "oracle", "cpu_calibration.json")) as f:
+            cal = json.load(f)["cases"]
+        calib = {"port_over_reference_time": [c_["port_over_reference_time"] for c_ in cal], "cases": [c_["case"] for c_ in cal],
+                 "reference_tokens_per_s_in_build_container": [c_["reference_tokens_per_s"] for c_ in cal], "cores_there": cal[0]["cores"],
+                 "note": "the reference's own loop (shim-loaded, unmodified) and the port timed on the same model / prompt / cores in the build container, identical "
+                         "token streams: the port takes this fraction of the reference's time, i.e. `value` overstates the reference's speed by 1 / it"}
+        sample += (f"; calibration (oracle/cpu_calibration.json): the port takes {min(calib['port_over_reference_time']):.2f}-{max(calib['port_over_reference_time']):.2f} x the "
+                   f"time of the shim-loaded reference on the same model and cores")
+    except Exception:
+        pass
+    return {"value": round(1.0 / step_s, 4), "unit": "tokens/s", "cores": cores, "kind": "port", "sample": sample, "s_per_step": round(step_s, 4),
+            "calibration_vs_reference": calib}
 
 
 def worker(args):

@@ -60,94 +60,6 @@ __device__ void pool_insert_window(int32_t* pool_tok, int32_t* pool_cnt, int V, 
     }
 }
 
-// ---- the same W inserts with the pool rows staged in LDS (round 4) ---------------------------------------------------------
-// pool_insert_window is W dependent round trips to the pool in global memory: count, compare, shift, store - ~1 us each, 15.8 us of
-// the 7B step's tail.  The keys of a step are known up front (lst_token and level 0 of the window), so the count and the G x gs row of
-// every DISTINCT key are requested at once (one memory latency), the W sequential inserts - column order, duplicate keys sharing one
-// staged row: the order the reference's python list sees - run on LDS, and the rows go back in one sweep.  Columns are taken in chunks
-// that fit the staging area (W = 60, G = 60, N = 8: four chunks); a chunk is written back before the next one loads, so the
-// sequential semantics hold across chunks too.  Bit-exact against lru_insert (tests: the 99 reference pool states, churn at the ABI
-// limits, every golden end-to-end trace).
-constexpr int STG_ROW_INTS = 8192;          // 32 KB of pool rows
-
-// one insert on a staged row: the body of lru_insert on LDS (single wavefront: lane = slot)
-__device__ __forceinline__ void lru_insert_row(int32_t* slots, int32_t* cnt_p, int G, int gs, const int32_t* tup) {
-    const int lane = threadIdx.x;
-    const int cnt = *cnt_p;
-    bool match = lane < cnt;
-    for (int j = 0; j < gs && match; ++j) match = slots[lane * gs + j] == tup[j];
-    const uint64_t ball = __ballot(match);
-    __syncthreads();
-    if (ball == 0ull && cnt < G) {                       // append
-        if (lane < gs) slots[cnt * gs + lane] = tup[lane];
-        if (lane == 0) *cnt_p = cnt + 1;
-    } else {                                             // hit: move to the end; full without hit: drop the head
-        const int from = ball ? (__ffsll((unsigned long long)ball) - 1) : 0;
-        int32_t mv[LADE_MAX_LEVEL];
-        const bool shifts = lane >= from && lane + 1 < cnt;
-#pragma unroll
-        for (int j = 0; j < LADE_MAX_LEVEL; ++j)
-            if (shifts && j < gs) mv[j] = slots[(lane + 1) * gs + j];
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < LADE_MAX_LEVEL; ++j)
-            if (shifts && j < gs) slots[lane * gs + j] = mv[j];
-        if (lane < gs) slots[(cnt - 1) * gs + lane] = tup[lane];
-    }
-    __syncthreads();
-}
-
-struct PoolStage {
-    int32_t key[LADE_MAX_WINDOW];
-    int32_t own[LADE_MAX_WINDOW];          // chunk column whose staged row serves this column (the first one with the same key); -1: no valid key
-    int32_t cnt[LADE_MAX_WINDOW];
-    int32_t rows[STG_ROW_INTS];
-};
-
-// win: the window BEFORE the roll ([N-1][wcap], LDS or global); new_results [W]
-__device__ void pool_insert_window_staged(int32_t* pool_tok, int32_t* pool_cnt, int V, int G, int gs, int lst_token, const int32_t* win,
-                                          int wcap, const int32_t* new_results, int W, int N, int32_t* tup_sm, PoolStage& st) {
-    const int lane = threadIdx.x;
-    if (G <= 0) return;
-    const int row_ints = G * gs;
-    const int C = min(W, STG_ROW_INTS / row_ints);       // G <= 64, gs <= 15: at least 8 columns per chunk
-    for (int c0 = 0; c0 < W; c0 += C) {
-        const int n = min(C, W - c0);
-        for (int i = lane; i < n; i += 64) st.key[i] = (c0 + i == 0) ? lst_token : win[c0 + i - 1];
-        __syncthreads();
-        for (int i = lane; i < n; i += 64) {
-            const int key = st.key[i];
-            int own = -1;
-            if (key >= 0 && key < V) {
-                own = i;
-                for (int j = 0; j < i; ++j)
-                    if (st.key[j] == key) { own = j; break; }
-            }
-            st.own[i] = own;
-            if (own == i) st.cnt[i] = pool_cnt[key];
-        }
-        __syncthreads();
-        for (int idx = lane; idx < n * row_ints; idx += 64) {          // every row load of the chunk in flight together
-            const int i = idx / row_ints, e = idx - i * row_ints;
-            if (st.own[i] == i) st.rows[idx] = pool_tok[(size_t)st.key[i] * row_ints + e];
-        }
-        __syncthreads();
-        for (int i = 0; i < n; ++i) {
-            if (lane < gs) tup_sm[lane] = (lane < gs - 1) ? win[(lane + 1) * wcap + c0 + i] : new_results[c0 + i];
-            __syncthreads();
-            const int own = st.own[i];
-            if (own >= 0) lru_insert_row(st.rows + own * row_ints, &st.cnt[own], G, gs, tup_sm);
-        }
-        for (int idx = lane; idx < n * row_ints; idx += 64) {
-            const int i = idx / row_ints, e = idx - i * row_ints;
-            if (st.own[i] == i && e < st.cnt[i] * gs) pool_tok[(size_t)st.key[i] * row_ints + e] = st.rows[idx];
-        }
-        for (int i = lane; i < n; i += 64)
-            if (st.own[i] == i) pool_cnt[st.key[i]] = st.cnt[i];
-        __syncthreads();
-    }
-}
-
 __global__ __launch_bounds__(64) void pool_insert_window_kernel(int32_t* pool_tok, int32_t* pool_cnt, int V, int G, int gs,
                                                                 const int32_t* lst_token, const int32_t* window, int wcap,
                                                                 const int32_t* new_results, int W, int N) {
@@ -474,16 +386,8 @@ __global__ __launch_bounds__(64) void greedy_post_step_kernel(int32_t* ctl, int3
     __shared__ int32_t hits[LADE_MAX_LEVEL];
     __shared__ int32_t ng[LADE_MAX_LEVEL + 1];
     __shared__ int32_t rec_s[LADE_REC_WORDS];
-    __shared__ int32_t s_win[(LADE_MAX_LEVEL - 1) * LADE_MAX_WINDOW];
-    __shared__ int32_t s_new[LADE_MAX_WINDOW];
-    __shared__ PoolStage stage;
     const int gs = N - 1;
     const int lane = threadIdx.x;
-    // steady step: the window and the new level are staged in LDS while the control words arrive (independent loads, one latency)
-    if (phase == 2) {
-        for (int i = lane; i < (N - 1) * wcap; i += 64) s_win[i] = window[i];
-        for (int i = lane; i < W; i += 64) s_new[i] = am[1 + i];
-    }
     const int g = ctl[LADE_CTL_G];
     const int P = ctl[LADE_CTL_P];
     const int n_input = ctl[LADE_CTL_N_INPUT];
@@ -506,22 +410,11 @@ __global__ __launch_bounds__(64) void greedy_post_step_kernel(int32_t* ctl, int3
             verify_greedy(first_guess, guess, am_guess, g, gs, &max_hit, &max_hit_idx, hits);
             __syncthreads();
         }
-        __syncthreads();
-        pool_insert_window_staged(pool_tok, pool_cnt, V, G, gs, lst_token, s_win, wcap, s_new, W, N, tup, stage);
-        // window roll (lade/decoding.py:1119-1124) on the staged copy, one write-back
-        for (int l = 0; l < N - 2; ++l) {
-            const int off = (l == 0) ? 1 : 0;
-            for (int i = lane; i < W - off; i += 64) s_win[l * wcap + i] = s_win[(l + 1) * wcap + i + off];
-            __syncthreads();
-        }
-        for (int i = lane; i < W; i += 64) s_win[(N - 2) * wcap + i] = s_new[i];
-        __syncthreads();
-        for (int i = lane; i < (N - 1) * wcap; i += 64) window[i] = s_win[i];
-        if (lane == 0) {
-            ctl[LADE_CTL_WLEN] = W - 1;
-            for (int l = 1; l < N - 1; ++l) ctl[LADE_CTL_WLEN + l] = W;
-        }
-        __syncthreads();
+        // (round 4 staged the W pool rows and the window in LDS - all loads in one latency, the sequential inserts on LDS: measured 26-30 us
+        // against 16.6 us for this form; the in-kernel timeline put 2.2 k cycles on every LDS insert (gs is a run-time value: the unrolled
+        // guards cost more than the global round trips they replaced) and 3 us on the write-back.  Dropped: profiles/r4_post_step_bench.txt)
+        pool_insert_window(pool_tok, pool_cnt, V, G, gs, lst_token, window, wcap, inp_am, W, N, tup);
+        window_roll(window, wcap, ctl, inp_am, W, N);
         if (level_override) {                                   // filter_window (lade/decoding.py:131-135, :578-580)
             for (int i = lane; i < W; i += 64)
                 if (level_override[i] >= 0) window[(N - 2) * wcap + i] = level_override[i];
@@ -576,9 +469,11 @@ __global__ __launch_bounds__(64) void greedy_post_step_kernel(int32_t* ctl, int3
     __syncthreads();
     if (lane < LADE_REC_WORDS) {
         record[lane] = rec_s[lane];
-        if (record_host) record_host[lane] = rec_s[lane];        // pinned host memory mapped into the device: visible without a copy node
+        // pinned host memory mapped into the device: the stores leave the chip as they are issued (fine-grained host memory is not
+        // cached in L2) - no system-scope fence (it would write the XCD's whole dirty L2 back first, several us); the seal is what
+        // tells the polling host that all 24 words have landed
+        if (record_host) record_host[lane] = rec_s[lane];
     }
-    if (record_host) __threadfence_system();
 }
 
 // ---- lookahead parallelism: one fixed int32 record per rank per step ------------------------------

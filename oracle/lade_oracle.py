@@ -356,11 +356,29 @@ class OracleLlama:
         self.H, self.Hkv, self.d = cfg["heads"], cfg["kv_heads"], cfg["head_dim"]
         cos, sin = rope_tables(self.d, cfg["max_pos"], cfg.get("rope_theta", 10000.0))
         self.cos, self.sin = cos.to(dtype), sin.to(dtype)
+        # LlamaDynamicNTKScalingRotaryEmbedding (modeling_llama.py:292-318): the tables are REBUILT, with a base that grows with the
+        # sequence, whenever a step's kv_seq_len = P + T (:502-510) exceeds the longest length seen so far; cached K rows keep the
+        # rotation they were written with.  max_seq_len_cached starts at max_position_embeddings (:243-246).
+        sc = cfg.get("rope_scaling") or {}
+        self._ntk_factor = float(sc["factor"]) if sc.get("type", sc.get("rope_type")) == "dynamic" else None
+        self._rope_cached_len = cfg["max_pos"]
         self.vocab_size = cfg["vocab"]
 
     def new_cache(self):
         return [[torch.zeros(self.Hkv, 0, self.d, dtype=self.dtype), torch.zeros(self.Hkv, 0, self.d, dtype=self.dtype)]
                 for _ in range(self.L)]
+
+    def _rope_update(self, seq_len: int) -> None:
+        """_set_cos_sin_cache of the dynamic-NTK embedding (modeling_llama.py:299-316), called like forward() calls it (:260-261)"""
+        if seq_len <= self._rope_cached_len:
+            return
+        self._rope_cached_len = seq_len
+        d, mp = self.d, self.cfg["max_pos"]
+        base = self.cfg.get("rope_theta", 10000.0)
+        if seq_len > mp:
+            base = base * ((self._ntk_factor * seq_len / mp) - (self._ntk_factor - 1)) ** (d / (d - 2))
+        cos, sin = rope_tables(d, seq_len, base)
+        self.cos, self.sin = cos.to(self.dtype), sin.to(self.dtype)
 
     def _rms(self, x, w):
         v = x.float().pow(2).mean(-1, keepdim=True)
@@ -371,6 +389,8 @@ class OracleLlama:
         returns the final-normed hidden states [T, hid]."""
         w = self.w
         T = len(ids)
+        if self._ntk_factor is not None:
+            self._rope_update(cache[0][0].shape[1] + T)
         pos = torch.as_tensor(list(positions), dtype=torch.long)
         x = w["embed"][torch.as_tensor(list(ids), dtype=torch.long)]
         for i in range(self.L):

@@ -166,7 +166,7 @@ def build_ref_model(cfg, weights):
                      eos_token_id=2, tie_word_embeddings=False, head_dim=cfg["head_dim"])
     hc._attn_implementation = "eager"
     hc.rope_theta = cfg["rope_theta"]
-    hc.rope_scaling = None
+    hc.rope_scaling = cfg.get("rope_scaling")            # None | {"type": "linear" | "dynamic", "factor": f}  (modeling_llama.py:431-456)
     hc.pretraining_tp = 1
     hc.attention_bias = False
     hc.attention_dropout = 0.0
@@ -363,6 +363,24 @@ def gen_e2e_unlimited():
         print("unlimited", mname, "steps", steps, "gen", gen)
     dump("e2e_unlimited.json", {"runs": runs})
 
+def gen_e2e_dynamic_ntk():
+    """rope_scaling = {"type": "dynamic"} (LlamaDynamicNTKScalingRotaryEmbedding, modeling_llama.py:292-318): max_position_embeddings far
+    below the generated length, so the tables are rebuilt - with a new base - at nearly every step.  Greedy lookahead runs + the plain
+    greedy stream of the same model (which rebuilds at different lengths: the two streams need not agree, and are not required to)."""
+    runs = []
+    for (mname, pname, W, N, G, new, seed, pfp, mp, factor) in [("tiny-d64", "rep", 5, 4, 5, 56, 1, 0, 24, 2.0), ("tiny-d16", "rnd", 4, 3, 4, 48, 2, 1, 32, 4.0)]:
+        cfg = make_config(mname, max_pos=mp, rope_scaling={"type": "dynamic", "factor": factor})
+        w = random_weights_numpy(cfg, **MODELS[mname])
+        model = build_ref_model(cfg, w)
+        prompt = [t % cfg["vocab"] for t in PROMPTS[pname]]
+        toks, steps, gen, rec = run_ref_greedy(model, prompt, W, N, G, len(prompt) + new, seed, pfp, None, ())
+        runs.append({"model": mname, "model_seed": MODELS[mname]["seed"], "std": MODELS[mname]["std"], "prompt": prompt, "W": W, "N": N, "G": G,
+                     "max_length": len(prompt) + new, "seed": seed, "pool_from_prompt": pfp, "eos": None, "tokens": toks, "steps": steps,
+                     "generated": gen, "max_pos": mp, "rope_scaling": cfg["rope_scaling"], "plain": None, "equals_plain_greedy": None, "trace": rec.steps})
+        print("dynamic-ntk", mname, "max_pos", mp, "factor", factor, "steps", steps, "gen", gen, "S", round(gen / steps, 2),
+              "longest step", max(st["step_len"] for st in rec.steps))
+    dump("e2e_dynamic_ntk.json", {"runs": runs})
+
 # ------------------------------------------------------------------ sampling
 
 
@@ -530,3 +548,5 @@ if __name__ == "__main__":
         gen_e2e_greedy_wide()
     if "sample_eos" in what:
         gen_e2e_sample_eos()
+    if "dynamic_ntk" in what:          # round 4: a separate fixture, the others stay byte-identical
+        gen_e2e_dynamic_ntk()
