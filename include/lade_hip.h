@@ -147,6 +147,18 @@ int lade_mask_render(const lade_mask_params* m, uint8_t* out, void* stream);
 
 /* ---- RoPE + KV append, KV commit ----------------------------------------------------- */
 
+/* rope_scaling "dynamic" (LlamaDynamicNTKScalingRotaryEmbedding, lade/models/modeling_llama.py:292-318): the cos / sin rows of ONE step.
+ * The reference rebuilds its tables with a sequence-dependent base whenever kv_seq_len = P + T (:502-510) exceeds the longest length seen;
+ * here state[0] (device int32, initialised to max_position_embeddings, reset with the sequence) carries that length, inv_tab
+ * [n_len][d/2] (fp32, host-built like the reference builds inv_freq) holds the inverse frequencies of a rebuild at length
+ * max_position_embeddings + i, and the kernel writes cos_rows / sin_rows [T][d] (model dtype) for the step's T positions - the rope
+ * entry points below are then called with positions = 0..T-1 and these rows as their tables.  len_hint: a longer length the step
+ * belongs to (chunked prefill: the reference sees the whole prompt at once), 0 otherwise.  P from dyn_P when non-null.  g_dev (nullable):
+ * the step is a hipGraph step padded to gcap candidates of gs rows of which only *g_dev exist - the length counts the real rows. */
+int lade_rope_rows_dynamic(const int32_t* positions, int32_t T, int32_t P, const int32_t* dyn_P, int32_t len_hint, int32_t* state,
+                           int32_t max_position_embeddings, const float* inv_tab, int32_t n_len, int32_t d, void* cos_rows, void* sin_rows,
+                           int32_t dtype, const int32_t* g_dev, int32_t gcap, int32_t gs, void* stream);
+
 /* qkv: [T][(H+2*Hkv)*d] fused projection output.  Rotates q in place and writes the rotated k
  * and v of token t into cache row P+t.  cos/sin: [max_pos][d] tables in the model dtype, built
  * as the reference builds them (fp32 math, then cast; modeling_llama.py:248-256); the rotation

@@ -61,6 +61,7 @@ SIGNATURES = {
     "lade_attn_combine": [C.POINTER(AttnArgs), _vp],
     "lade_mask_render": [C.POINTER(MaskParams), _vp, _vp],
     "lade_rope_kv_append": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "lade_rope_rows_dynamic": [_vp, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _vp],
     "lade_kv_commit": [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp],
     "lade_build_inputs": [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp],
     "lade_argmax_rows": [_vp, _i64, _i32, _i32, _i32, _vp, _vp],

@@ -207,9 +207,54 @@ static int launch_rope(void* qkv, const int32_t* positions, const void* cos_tab,
     return check_launch("lade_rope_kv_append");
 }
 
+// LlamaDynamicNTKScalingRotaryEmbedding (lade/models/modeling_llama.py:292-318) for one step: the reference rebuilds its cos / sin tables -
+// with a base that grows with the sequence - whenever a step's kv_seq_len = P + T (:502-510) exceeds the longest length it has seen
+// (`max_seq_len_cached`, starting at max_position_embeddings), and leaves cached K rows with the rotation they were written with.  A step
+// only ever gathers the rows of its own T positions, so this kernel writes exactly those T rows (cos_rows / sin_rows [T][d], then indexed
+// by the token's row instead of its position) from the device-resident state: state[0] = longest length seen.  inv_tab[i][d/2] = the
+// inverse frequencies of a table rebuilt at length mp + i (row 0: the original base), computed on the host by torch exactly as the
+// reference computes them (`base ** (arange / dim)` in fp32), so that only the final cos / sin come from this device.
+template <typename T>
+__global__ __launch_bounds__(128) void rope_rows_dynamic_kernel(const int32_t* positions, int T_, int P, const int32_t* dyn_P, int len_hint,
+                                                                int32_t* state, int mp, const float* inv_tab, int n_len, int d,
+                                                                typename Elem<T>::S* cos_rows, typename Elem<T>::S* sin_rows,
+                                                                const int32_t* g_dev, int gcap, int gs) {
+    const int t = blockIdx.x, j = threadIdx.x;
+    if (dyn_P) P = *dyn_P;
+    int T_real = T_;
+    if (g_dev) T_real -= (gcap - min(max(*g_dev, 0), gcap)) * gs;      // a hipGraph step padded to gcap candidates: only g of them exist
+    const int seen = *state;
+    int eff = max(seen, max(P + T_real, len_hint));          // every block computes the same value: the write-back below is idempotent
+    const int idx = min(max(eff - mp, 0), n_len - 1);
+    if (j < d / 2) {
+        const float ang = (float)positions[t] * inv_tab[(size_t)idx * (d / 2) + j];
+        const typename Elem<T>::S c = Elem<T>::st(cosf(ang)), sn = Elem<T>::st(sinf(ang));
+        cos_rows[(size_t)t * d + j] = c;
+        cos_rows[(size_t)t * d + j + d / 2] = c;
+        sin_rows[(size_t)t * d + j] = sn;
+        sin_rows[(size_t)t * d + j + d / 2] = sn;
+    }
+    if (t == 0 && j == 0 && eff != seen) *state = eff;
+}
+
 }  // namespace lade
 
 using namespace lade;
+
+extern "C" int lade_rope_rows_dynamic(const int32_t* positions, int32_t T, int32_t P, const int32_t* dyn_P, int32_t len_hint, int32_t* state,
+                                      int32_t max_position_embeddings, const float* inv_tab, int32_t n_len, int32_t d, void* cos_rows,
+                                      void* sin_rows, int32_t dtype, const int32_t* g_dev, int32_t gcap, int32_t gs, void* stream) {
+    LADE_REQUIRE(positions && state && inv_tab && cos_rows && sin_rows && T > 0 && P >= 0 && n_len > 0 && max_position_embeddings > 0 && d > 0 && d % 2 == 0 &&
+                     d <= 256, LADE_E_ARG, "lade_rope_rows_dynamic: T=%d P=%d n_len=%d d=%d", T, P, n_len, d);
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case LADE_BF16: hipLaunchKernelGGL(rope_rows_dynamic_kernel<BF16>, dim3(T), dim3(128), 0, st, positions, T, P, dyn_P, len_hint, state, max_position_embeddings, inv_tab, n_len, d, (uint16_t*)cos_rows, (uint16_t*)sin_rows, g_dev, gcap, gs); break;
+        case LADE_F16: hipLaunchKernelGGL(rope_rows_dynamic_kernel<F16>, dim3(T), dim3(128), 0, st, positions, T, P, dyn_P, len_hint, state, max_position_embeddings, inv_tab, n_len, d, (uint16_t*)cos_rows, (uint16_t*)sin_rows, g_dev, gcap, gs); break;
+        case LADE_F32: hipLaunchKernelGGL(rope_rows_dynamic_kernel<F32>, dim3(T), dim3(128), 0, st, positions, T, P, dyn_P, len_hint, state, max_position_embeddings, inv_tab, n_len, d, (float*)cos_rows, (float*)sin_rows, g_dev, gcap, gs); break;
+        default: LADE_REQUIRE(false, LADE_E_DTYPE, "lade_rope_rows_dynamic: dtype=%d", dtype);
+    }
+    return check_launch("lade_rope_rows_dynamic");
+}
 
 extern "C" int lade_rope_kv_append(void* qkv, const int32_t* positions, const void* cos_tab, const void* sin_tab,
                                    void* k_cache, void* vt_cache, int32_t T, int32_t P, const int32_t* dyn_P, int32_t H,

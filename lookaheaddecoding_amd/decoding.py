@@ -190,7 +190,8 @@ class LookaheadDecoder:
         T = mask.T
         call("lade_build_inputs", None, None, 1, ptr(st.window), st.wcap, ptr(st.ctl), N - 2, 0, -1, ptr(st.guess), -1, gs, cand_rows,
              ptr(st.ids), ptr(st.pos), None, 0, 1)
-        logits = e.forward(st.ids, st.pos, mask, self._graph_sel[gcap], 1 + W + cand_rows, dyn_P=st.ctl, n_splits=self._graph_splits[gcap])
+        logits = e.forward(st.ids, st.pos, mask, self._graph_sel[gcap], 1 + W + cand_rows, dyn_P=st.ctl, n_splits=self._graph_splits[gcap],
+                           ntk_pad=(st.ctl[CTL_G:CTL_G + 1], gcap, gs))      # (dynamic-NTK RoPE only: the padded candidate slots are not sequence length)
         ops.argmax_rows(logits, out=st.am)
         if forward_only:
             return logits.float()                                   # logits.float(), modeling_llama.py:1544
@@ -207,7 +208,7 @@ class LookaheadDecoder:
         e, st = self.e, self.st
         W, N, gs = self.W, self.N, self.gs
         self._graphs, self._graph_sel, self._graph_splits, self._graph_T, self._graph_logits = {}, {}, {}, {}, {}
-        state = (st.ctl, st.window, st.pool_cnt, st.pool_tok, st.guess, st.tail)
+        state = (st.ctl, st.window, st.pool_cnt, st.pool_tok, st.guess, st.tail) + (() if e.ntk_state is None else (e.ntk_state,))
         saved = [t.clone() for t in state]
         for gcap in self._buckets():
             cand_rows = gcap * gs

@@ -48,10 +48,22 @@ def rope_inv_freq(d: int, theta: float, scaling: Optional[dict] = None) -> torch
         blended = (1 - smooth) * scaled / factor + smooth * scaled
         medium = ~(wavelen < old_len / hi) & ~(wavelen > old_len / lo)
         inv_freq = torch.where(medium, blended, scaled)
-    elif kind not in (None, "default", "linear"):
-        raise cabi.LadeHipError(f"rope_scaling type {kind!r} is not implemented (default, linear and llama3 are; 'dynamic' rebuilds its "
-                                f"tables as the sequence grows, lade/models/modeling_llama.py:292-318, and is refused rather than approximated)")
+    elif kind not in (None, "default", "linear", "dynamic"):       # dynamic: the per-step rows come from StepEngine._ntk (lade_rope_rows_dynamic)
+        raise cabi.LadeHipError(f"rope_scaling type {kind!r} is not implemented (default, linear, dynamic and llama3 are)")
     return inv_freq
+
+
+def ntk_inv_freq_table(d: int, theta: float, factor: float, max_position_embeddings: int, S_max: int) -> torch.Tensor:
+    """[n_len, d/2] fp32: row i = the inv_freq LlamaDynamicNTKScalingRotaryEmbedding._set_cos_sin_cache computes when it rebuilds at
+    seq_len = max_position_embeddings + i (lade/models/modeling_llama.py:302-308; row 0 = the original base), with torch's own fp32 pow
+    so that the values are the reference's."""
+    mp = max_position_embeddings
+    ar = torch.arange(0, d, 2).float() / d
+    rows = [1.0 / (theta ** ar)]
+    for L in range(mp + 1, max(S_max, mp) + 1):
+        base = theta * ((factor * L / mp) - (factor - 1)) ** (d / (d - 2))
+        rows.append(1.0 / (base ** ar))
+    return torch.stack(rows).contiguous()
 
 
 def rope_tables(d: int, max_pos: int, theta: float, dtype, device, scaling: Optional[dict] = None):
@@ -290,6 +302,16 @@ class StepEngine:
         self.S_max = S_max
         self.cos, self.sin = rope_tables(self.d, max(self.cfg.get("max_pos", 4096), S_max), self.cfg.get("rope_theta", 10000.0), dt, dev,
                                          self.cfg.get("rope_scaling"))
+        # rope_scaling "dynamic" (LlamaDynamicNTKScalingRotaryEmbedding, lade/models/modeling_llama.py:292-318): the tables above are never
+        # read; every step gets the cos / sin rows of its own positions from the device-resident "longest length seen" (lade_rope_rows_dynamic)
+        sc = self.cfg.get("rope_scaling") or {}
+        prev = getattr(self, "_ntk", None)
+        self._ntk = None
+        if sc.get("rope_type", sc.get("type")) == "dynamic":
+            mp = int(self.cfg.get("max_pos", 4096))
+            tab = ntk_inv_freq_table(self.d, self.cfg.get("rope_theta", 10000.0), float(sc["factor"]), mp, S_max).to(dev)
+            state = prev["state"] if prev is not None else torch.full((1,), mp, dtype=torch.int32, device=dev)
+            self._ntk = dict(mp=mp, inv_tab=tab, state=state, rows=None)
         self.kv = torch.zeros(self.L, 2, self.Hkv * S_max * self.d, dtype=dt, device=dev)
         self.kv._lade_meta = dict(Hkv=self.Hkv, d=self.d, S_max=S_max)
         # per-layer views built once: an eager step issues ~10 launches per layer and must not spend its time in tensor indexing
@@ -342,6 +364,28 @@ class StepEngine:
 
     def reset(self) -> None:
         self.kv.zero_()
+        if self._ntk is not None:
+            self._ntk["state"].fill_(self._ntk["mp"])          # a new sequence: max_seq_len_cached = max_position_embeddings again
+
+    @property
+    def ntk_state(self) -> Optional[torch.Tensor]:
+        """device int32[1]: the longest kv_seq_len the dynamic-NTK rotary embedding has seen (None without `rope_scaling: dynamic`) - part
+        of the sequence's state: whoever runs a throw-away forward (graph warm-up, tuning probe) saves and restores it"""
+        return None if self._ntk is None else self._ntk["state"]
+
+    def _ntk_rows(self, pos: torch.Tensor, T: int, P: int, dyn_P, rope_len: int, pad=None):
+        """cos / sin rows of this step's T positions under dynamic NTK scaling; returns (row index 0..T-1, cos_rows, sin_rows) for the rope kernels.
+        pad = (g_dev, gcap, gs): a hipGraph step padded to gcap candidates counts only its real rows (T - (gcap - g) gs), as the reference's
+        kv_seq_len does."""
+        nt = self._ntk
+        if nt["rows"] is None or nt["rows"][0].shape[0] < self.max_T:
+            nt["rows"] = (torch.empty(self.max_T, self.d, dtype=self.dtype, device=self.device), torch.empty(self.max_T, self.d, dtype=self.dtype, device=self.device),
+                          torch.arange(self.max_T, dtype=torch.int32, device=self.device))
+        cos_r, sin_r, iota = nt["rows"]
+        g_dev, gcap, gs = pad if pad is not None else (None, 0, 1)
+        cabi.call("lade_rope_rows_dynamic", cabi.ptr(pos), T, P, cabi.ptr(dyn_P), int(rope_len), cabi.ptr(nt["state"]), nt["mp"], cabi.ptr(nt["inv_tab"]),
+                  nt["inv_tab"].shape[0], self.d, cabi.ptr(cos_r), cabi.ptr(sin_r), cabi.dtype_code(cos_r), cabi.ptr(g_dev), gcap, gs)
+        return iota, cos_r, sin_r
 
     def n_splits_for(self, T: int, S_tot: int) -> int:
         if self.dtype == torch.float32:
@@ -614,6 +658,7 @@ class StepEngine:
         n_splits = self.n_splits_for(T, P + T)
         all_layers = self.layers
         kv_saved = [(self._k_views[li][:, P:P + T].clone(), self._vt_views[li][:, :, P:P + T].clone()) for li in range(n_probe)]
+        ntk_saved = None if self.ntk_state is None else self.ntk_state.clone()
         saved_ev, self.attn_events = self.attn_events, None
         choice, log = {}, {}
         self._refining = True
@@ -661,6 +706,8 @@ class StepEngine:
             for li, (k, v) in enumerate(kv_saved):
                 self._k_views[li][:, P:P + T].copy_(k)
                 self._vt_views[li][:, :, P:P + T].copy_(v)
+            if ntk_saved is not None:
+                self.ntk_state.copy_(ntk_saved)
             torch.cuda.synchronize()
         return choice, log
 
@@ -688,7 +735,7 @@ class StepEngine:
     # ---- one forward -----------------------------------------------------------------------------
     @_on_device
     def forward(self, ids: torch.Tensor, pos: torch.Tensor, mask: StepMask, sel_rows: torch.Tensor, n_sel: int,
-                dyn_P: Optional[torch.Tensor] = None, n_splits: Optional[int] = None) -> torch.Tensor:
+                dyn_P: Optional[torch.Tensor] = None, n_splits: Optional[int] = None, rope_len: int = 0, ntk_pad=None) -> torch.Tensor:
         """ids/pos: device int32 [>=T]; mask describes the step; sel_rows: device int32 [n_sel] rows whose
         logits are needed.  Appends the T new K/V rows at P..P+T and returns logits [n_sel, V] (model dtype,
         as `self.lm_head(hidden_states)` does at lade/models/modeling_llama.py:1541)."""
@@ -711,6 +758,7 @@ class StepEngine:
                 self._refine_in_step(mclass)
                 cfg_qkv, cfg_o, cfg_gu, cfg_d = (self.gemm_cfg[(n, mclass)] for n in self.LAYER_GEMMS)
         ops.gather_rows(self.embed, ids, out=x, rows=T)
+        rpos, rcos, rsin = (pos, self.cos, self.sin) if self._ntk is None else self._ntk_rows(pos, T, P, dyn_P, rope_len, ntk_pad)
         part = self.ws_part if fused else None
         r_parts = 0                     # > 0: the pending residual branch lives in `part` as that many split-K partials
         for li, lw in enumerate(self.layers):
@@ -723,11 +771,11 @@ class StepEngine:
             if cfg_qkv:
                 ops.gemm_parts(h, self._w(lw, "wqkv"), part, cfg_qkv[2], cfg_qkv[1], cfg_qkv[0], cfg_qkv[3], cfg_qkv[4], cfg_qkv[5])
                 qb = self.ws_q[:T]
-                ops.rope_kv_append_parts(part, cfg_qkv[2], qb, pos, self.cos, self.sin, self.k_cache(li), self.vt_cache(li), T, P, H=H, Hkv=Hkv, d=d, dyn_P=dyn_P)
+                ops.rope_kv_append_parts(part, cfg_qkv[2], qb, rpos, rcos, rsin, self.k_cache(li), self.vt_cache(li), T, P, H=H, Hkv=Hkv, d=d, dyn_P=dyn_P)
                 q_in = qb
             else:
                 torch.matmul(h, self._row(lw, "wqkv").t(), out=qkv)
-                ops.rope_kv_append(qkv, pos, self.cos, self.sin, self.k_cache(li), self.vt_cache(li), P, H=H, Hkv=Hkv, d=d, dyn_P=dyn_P)
+                ops.rope_kv_append(qkv, rpos, rcos, rsin, self.k_cache(li), self.vt_cache(li), P, H=H, Hkv=Hkv, d=d, dyn_P=dyn_P)
                 q_in = qkv
             ev = None if self.skip_attn else self.attn_events      # skip_attn: `o` keeps stale values, the logits are meaningless
             if ev is not None:              # bench.py: hipEvents around the attention launch pair, in the real step
@@ -806,11 +854,12 @@ class StepEngine:
         done = 0
         while total - done > last_len:
             n = min(self.max_T, total - last_len - done)
-            self.forward(t_ids[done:done + n], t_pos[done:done + n], StepMask(T=n, P=P0 + done, is_prefill=True), none_sel, 0)
+            self.forward(t_ids[done:done + n], t_pos[done:done + n], StepMask(T=n, P=P0 + done, is_prefill=True), none_sel, 0, rope_len=P0 + total)
             done += n
         sel = torch.tensor([int(r) - done for r in rows], dtype=torch.int32).to(dev, non_blocking=True)
         T = total - done
-        logits = self.forward(t_ids[done:], t_pos[done:], StepMask(T=T, P=P0 + done, is_prefill=True), sel, len(rows))
+        # (rope_len: under dynamic NTK scaling the reference sees the whole prompt in ONE forward, kv_seq_len = P0 + total; the chunks must too)
+        logits = self.forward(t_ids[done:], t_pos[done:], StepMask(T=T, P=P0 + done, is_prefill=True), sel, len(rows), rope_len=P0 + total)
         return logits, done
 
     # ---- plain causal decoding on the same kernels (the sequence lookahead must reproduce) ------

@@ -52,10 +52,9 @@ def config_from_hf(model) -> dict:
     theta, scaling = _rope_params(c)
     if scaling is not None:
         kind = scaling.get("rope_type", scaling.get("type"))
-        if kind not in ("linear", "llama3"):
-            # 'dynamic' (LlamaDynamicNTKScalingRotaryEmbedding, lade/models/modeling_llama.py:292-318) rebuilds its tables as the
-            # sequence grows; it is refused here rather than approximated
-            raise cabi.LadeHipError(f"rope_scaling type {kind!r} is not implemented by the HIP step (default, linear and llama3 are)")
+        if kind not in ("linear", "llama3", "dynamic"):
+            # ('dynamic' = LlamaDynamicNTKScalingRotaryEmbedding, lade/models/modeling_llama.py:292-318: per-step rows, engine._ntk_rows)
+            raise cabi.LadeHipError(f"rope_scaling type {kind!r} is not implemented by the HIP step (default, linear, dynamic and llama3 are)")
     if getattr(c, "attention_bias", False) or getattr(c, "mlp_bias", False):
         raise cabi.LadeHipError("projection biases are not supported (Llama-2 has none)")
     if getattr(c, "pretraining_tp", 1) not in (None, 1):

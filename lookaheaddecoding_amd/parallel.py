@@ -410,7 +410,8 @@ class LPRunner:
             level_lens = [W + N - 3 - fill_level] + [W + N - 2 - fill_level] * fill_level
         c0, c1 = window_shard(level_lens[0] + 1, R, r)
         glo, ghi = guess_shard(self.g, R, r) if phase == 2 else (0, 0)
-        if phase == 2 and getattr(self.dec, "use_graph", False) and hasattr(self.be, "local_step_graph"):
+        # (dynamic-NTK RoPE: a padded graph segment would count its padding as sequence length - those models take the eager LP step)
+        if phase == 2 and getattr(self.dec, "use_graph", False) and hasattr(self.be, "local_step_graph") and getattr(self.dec.e, "ntk_state", None) is None:
             rec = self.be.local_step_graph(self.P, self.n_input, level_lens, c0, c1, ghi - glo)
         else:
             rec = self.be.local_step(phase, self.P, self.n_input, level_lens, c0, c1, self.g, glo, ghi)

@@ -274,3 +274,24 @@ def test_cache_exhaustion_raises_and_never_writes_past_the_cache(use_graph):
     assert len(got) > len(prompt) + 40                      # it ran until the cache was nearly full
     big = StepEngine(cfg, w, dtype=torch.float32, max_seq=512, max_T=64)
     assert big.plain_greedy(prompt, len(got)) == got
+
+
+def test_dynamic_ntk_rope_matches_reference_traces_eager_and_graph():
+    """rope_scaling = dynamic (lade/models/modeling_llama.py:292-318) on the HIP step: `lade_rope_rows_dynamic` keeps the reference's
+    "longest kv_seq_len seen" on the device and writes the step's cos / sin rows from it - fp32 engine vs the reference's own runs (tables
+    rebuilt at nearly every step, one run with non-monotone step lengths), eager and hipGraph (whose padded candidate slots must not count
+    as sequence length), tokens / steps / per-step cache lengths; and a second run on the same engine starts from the original tables again."""
+    from lookaheaddecoding_amd.decoding import LookaheadDecoder
+    from lookaheaddecoding_amd.engine import StepEngine
+    for run in load("e2e_dynamic_ntk.json")["runs"]:
+        cfg = make_config(run["model"], max_pos=run["max_pos"], rope_scaling=run["rope_scaling"])
+        w = {k: torch.as_tensor(v) for k, v in random_weights_numpy(cfg, seed=run["model_seed"], std=run["std"]).items()}
+        eng = StepEngine(cfg, w, dtype=torch.float32, max_seq=512, max_T=320)
+        assert eng.ntk_state is not None and int(eng.ntk_state.item()) == run["max_pos"]
+        for use_graph in (False, True, False):
+            dec = LookaheadDecoder(eng, run["W"], run["N"], run["G"], pool_from_prompt=bool(run["pool_from_prompt"]), use_graph=use_graph)
+            out = dec.greedy(run["prompt"], run["max_length"], rng=random.Random(run["seed"]), keep_trace=True)
+            assert out.tokens == run["tokens"] and out.steps == run["steps"], (run["model"], use_graph)
+            for i, (mine, ref) in enumerate(zip(out.trace, run["trace"])):
+                assert mine["T"] >= len(ref["ids"]) and mine["P_before"] == ref["P"] and mine["first_guess"] == ref["out_argmax"], (i, use_graph)
+            assert int(eng.ntk_state.item()) == max(st["step_len"] for st in run["trace"])

@@ -37,8 +37,13 @@ def test_unknown_rope_scaling_is_refused():
     from lookaheaddecoding_amd.engine import rope_tables
     with pytest.raises(cabi.LadeHipError):
         rope_tables(64, 128, 10000.0, torch.float32, "cpu", {"rope_type": "yarn", "factor": 2.0})
-    with pytest.raises(cabi.LadeHipError):
-        rope_tables(64, 128, 10000.0, torch.float32, "cpu", {"rope_type": "dynamic", "factor": 2.0})
+    # 'dynamic' is implemented since round 4 (per-step rows, lade_rope_rows_dynamic); its host-built inverse-frequency table is the
+    # reference's formula (lade/models/modeling_llama.py:302-308): row 0 the original base, row i a rebuild at length max_pos + i
+    from lookaheaddecoding_amd.engine import ntk_inv_freq_table
+    tab = ntk_inv_freq_table(64, 10000.0, 2.0, 32, 40)
+    assert tab.shape == (9, 32) and torch.equal(tab[0], 1.0 / (10000.0 ** (torch.arange(0, 64, 2).float() / 64)))
+    base = 10000.0 * ((2.0 * 40 / 32) - 1.0) ** (64 / 62)
+    assert torch.equal(tab[8], 1.0 / (base ** (torch.arange(0, 64, 2).float() / 64))) and bool((tab[8] <= tab[0]).all())
 
 
 def test_config_from_hf_guards():

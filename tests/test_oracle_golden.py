@@ -24,7 +24,7 @@ def tm_json(tm):
 
 
 def oracle_model(run):
-    cfg = make_config(run["model"], max_pos=512)
+    cfg = make_config(run["model"], max_pos=run.get("max_pos", 512), **({"rope_scaling": run["rope_scaling"]} if run.get("rope_scaling") else {}))
     w = random_weights_numpy(cfg, seed=run["model_seed"], std=run["std"])
     return O.OracleLlama(cfg, {k: torch.as_tensor(v) for k, v in w.items()})
 
@@ -134,6 +134,27 @@ def test_unlimited_guess_set_never_verifies_like_the_reference():
                                  eos_token_id=run["eos"], pool_from_prompt=bool(run["pool_from_prompt"]))
         _check_trace(res, run)
         assert res.steps == res.generated
+
+
+def test_dynamic_ntk_rope_matches_reference_traces():
+    """rope_scaling = dynamic (LlamaDynamicNTKScalingRotaryEmbedding, lade/models/modeling_llama.py:292-318): max_position_embeddings far
+    below the generated length, so the reference rebuilds its tables - new base - at nearly every step, on kv_seq_len = P + T with the
+    longest length kept (one run's step lengths go 42, 39, 39, 40: no rebuild there).  Tokens, steps and every step's inputs."""
+    d = load("e2e_dynamic_ntk.json")
+    assert len(d["runs"]) == 2
+    differs = []
+    for run in d["runs"]:
+        assert max(st["step_len"] for st in run["trace"]) > run["max_pos"] * 2
+        model = oracle_model(run)
+        res = O.lookahead_greedy(model, run["prompt"], run["W"], run["N"], run["G"], run["max_length"], random.Random(run["seed"]),
+                                 pool_from_prompt=bool(run["pool_from_prompt"]))
+        _check_trace(res, run)
+        # and the tables matter: the same run with the scaling switched off parts from the reference
+        plain_rope = O.OracleLlama(make_config(run["model"], max_pos=512), model.w)
+        other = O.lookahead_greedy(plain_rope, run["prompt"], run["W"], run["N"], run["G"], run["max_length"], random.Random(run["seed"]),
+                                   pool_from_prompt=bool(run["pool_from_prompt"]))
+        differs.append(other.tokens != run["tokens"])
+    assert any(differs)            # (a run whose tiny model is insensitive to the rotation may coincide; not both)
 
 
 def test_lookahead_parallel_matches_reference_gloo_runs():
