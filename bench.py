@@ -443,6 +443,26 @@ def worker(args):
                            "us_per_pair": [round((a - b) / cfg["layers"] * 1e3, 2) for a, b in pairs],
                            "ms_per_step_without_attention": round(sorted(b for _, b in pairs)[len(pairs) // 2], 3)}
 
+    # ---- how much of a step is the host's turn-around: the same steady step replayed back to back WITHOUT reading its record in between
+    # (legal while no candidate appears: the bucket-0 graph; the device state advances by itself) - the difference to ms_per_step is what
+    # the GPU waits for the host per step (record poll, bookkeeping, hipGraphLaunch)
+    gpu_only = None
+    if extras and dec.use_graph and getattr(dec, "_graphs", None) and dec.g == 0 and 0 in dec._graphs:
+        g0 = dec._graphs[0]
+        n_rep = args.steps
+        if dec.P + n_rep * 1 + dec._graph_T[0] + 8 <= eng.S_max:
+            sync()
+            tg0 = time.perf_counter()
+            for _ in range(n_rep):
+                g0.replay()
+            sync()
+            tg = (time.perf_counter() - tg0) / n_rep * 1e3
+            rec = dec.st.read_record()
+            cold = rec[3] == 0                                      # still no candidate at the end: every replay was a legal bucket-0 step
+            dec.P, dec.g, dec._step_no = rec[4], rec[3], rec[7]
+            gpu_only = {"ms_per_step_back_to_back": round(tg, 3), "host_turnaround_us_per_step": round((elapsed / args.steps * 1e3 - tg) * 1e3, 1),
+                        "valid": bool(cold), "how": f"{n_rep} replays of the steady step's hipGraph enqueued without waiting for the records in between"}
+
     # ---- plain autoregressive decoding on the same engine and cache length (one token per forward, T = 1): what lookahead
     # decoding has to beat; S * (plain step / lookahead step) is its speed-up
     plain = None
@@ -665,7 +685,7 @@ def worker(args):
             "prefill": {"tokens": args.prompt_len + W + N - 3, "ms": round(prefill_s * 1e3, 2), "tokens_per_s": round((args.prompt_len + W + N - 3) / prefill_s, 1),
                         "how": f"prompt + first window level as causal chunks of <= {args.chunk} rows through the same attention / GEMM kernels, lm_head on the "
                                "rows that are read only; second prefill of the process (the first one pays the one-off GEMM autotune)"},
-            "mid_regime": mid, "hot_regime": hot_l, "hot_regime_forced": hot, "plain_decode": plain, "roofline": roofline,
+            "mid_regime": mid, "hot_regime": hot_l, "hot_regime_forced": hot, "plain_decode": plain, "step_gpu_only": gpu_only, "roofline": roofline,
             # the whole step against the same HBM peak: the bytes a step cannot avoid reading (weights + K/V cache + lm_head) / its time
             "step_stream": {"bound": "hbm", "bytes_per_step": step_stream_bytes(cfg, P_end, 1), "achieved": round(step_stream_bytes(cfg, P_end, 1) / (elapsed / args.steps) / 1e9, 1),
                             "peak": 8000.0, "unit": "GB/s", "frac": round(step_stream_bytes(cfg, P_end, 1) / (elapsed / args.steps) / 1e9 / 8000.0, 4),

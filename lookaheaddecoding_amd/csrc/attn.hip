@@ -325,6 +325,30 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
     const uint16_t* kbase = a.k + (size_t)kvh * a.S_max * D;
     const uint16_t* vbase = a.vt + (size_t)kvh * D * a.S_max;
 
+    const int n_rows = n_rep * a.m.T;
+    const float invT = a.inv_T;
+    // row r of the (head-in-group, token) row space -> (hg, t); exact for r < 4096, T <= 512
+    auto split_row = [&](int r, int& hg, int& t) {
+        if (n_rep == 1) { hg = 0; t = r; }
+        else { hg = (int)(((float)r + 0.5f) * invT); t = r - hg * a.m.T; }
+    };
+    // the Q tile is requested FIRST: its addresses need nothing but the block id, so its pieces are on their way while the cache length
+    // (a dependent scalar load in hipGraph steps) is still in flight; the first counted wait covers the Q tile + stage 0 (Q is the oldest)
+#pragma unroll
+    for (int i = 0; i < QPW; ++i) {
+        const int piece = wave * QPW + i;
+        // a 32-row group without any row (a steady 7B step has 60 rows: groups 2 and 3 of the 128-row block) is not requested at all:
+        // its waves never read it (wave_rows below).  Pieces are wave uniform, the counted waits below do not depend on how many a wave issued.
+        if (rbk * ROWS + (piece * (64 / K_CPR) / 32) * 32 >= n_rows) continue;
+        const int row = piece * (64 / K_CPR) + lane / K_CPR;
+        const int c = (lane % K_CPR) ^ swz16<2 * D>(row);
+        int r = rbk * ROWS + row, hg, t;
+        if (r >= n_rows) r = 0;                       // rows past the end read row 0; never stored
+        split_row(r, hg, t);
+        const uint16_t* src = a.q + (size_t)t * a.q_row_stride + (size_t)(kvh * n_rep + hg) * D + c * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(q_lds + piece * 1024), 16, 0, 0);
+    }
     // ---- split geometry: split sp covers the 64-key tiles base, base+stride, ... (my_tiles of them)
     lade_mask_params m = a.m;
     if (a.dyn_P) m.P = *a.dyn_P;
@@ -392,29 +416,6 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
 #pragma unroll
     for (int ts = 0; ts < TPS; ++ts) issue_tiles(0, ts, ts < my_tiles ? base + ts * stride : base);
 
-    const int n_rows = n_rep * m.T;
-    const float invT = a.inv_T;
-    // row r of the (head-in-group, token) row space -> (hg, t); exact for r < 4096, T <= 512
-    auto split_row = [&](int r, int& hg, int& t) {
-        if (n_rep == 1) { hg = 0; t = r; }
-        else { hg = (int)(((float)r + 0.5f) * invT); t = r - hg * m.T; }
-    };
-    // the Q tile goes between stage 0 and the younger stages: the first counted wait covers exactly stage 0 + Q
-#pragma unroll
-    for (int i = 0; i < QPW; ++i) {
-        const int piece = wave * QPW + i;
-        // a 32-row group without any row (a steady 7B step has 60 rows: groups 2 and 3 of the 128-row block) is not requested at all:
-        // its waves never read it (wave_rows below).  Pieces are wave uniform, the counted waits below do not depend on how many a wave issued.
-        if (rbk * ROWS + (piece * (64 / K_CPR) / 32) * 32 >= n_rows) continue;
-        const int row = piece * (64 / K_CPR) + lane / K_CPR;
-        const int c = (lane % K_CPR) ^ swz16<2 * D>(row);
-        int r = rbk * ROWS + row, hg, t;
-        if (r >= n_rows) r = 0;                       // rows past the end read row 0; never stored
-        split_row(r, hg, t);
-        const uint16_t* src = a.q + (size_t)t * a.q_row_stride + (size_t)(kvh * n_rep + hg) * D + c * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(q_lds + piece * 1024), 16, 0, 0);
-    }
 #pragma unroll
     for (int s = 1; s < NSTG; ++s)
 #pragma unroll

@@ -114,6 +114,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
         const int c = (lane & 7) ^ ((row >> 1) & 7);
         p_src[i] = (isw ? g.W + (size_t)min(n0 + row, g.N - 1) * w_rs + (size_t)t0 * w_ts
                         : g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + (size_t)t0 * G_BK) + c * 8;
+        if (!isw && (g.dbg & 128)) p_src[i] = g.A + (lane & 7) * 8;        // ablation (tools/gemm_ingest_probe.py): every activation piece re-reads one cached 128-byte line
         p_dst[i] = (isw ? 0 : W_BYTES) + p * 1024;
         p_w[i] = isw;
     }
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
         unsigned char* sbase = smem + stage * STAGE;
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
-            const uint16_t* src = p_src[i] + (int64_t)j * (p_w[i] ? w_ts : (int64_t)G_BK);
+            const uint16_t* src = p_src[i] + (int64_t)j * (p_w[i] ? w_ts : ((g.dbg & 128) ? (int64_t)0 : (int64_t)G_BK));
             unsigned char* dst = sbase + p_dst[i];
             // the weight stream is non-temporal (aux = 2): every weight byte is read by exactly one work-group, once per step, so
             // keeping it in L2 / the Infinity Cache only evicts what is re-read (activation tiles, partials).  Measured on the four

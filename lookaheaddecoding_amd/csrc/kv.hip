@@ -4,6 +4,8 @@
 // the commit loop of lade/decoding.py:1154-1163.  The reference re-copies the whole cache with
 // torch.cat in every layer of every step; here the cache is preallocated ([Hkv][S_max][d] keys,
 // [Hkv][d][S_max] transposed values) and only the T new rows are written.
+#include <type_traits>
+
 #include "common.hpp"
 #include <algorithm>
 
@@ -73,29 +75,36 @@ __global__ __launch_bounds__(256) void rope_kv_append_kernel(typename Elem<T>::S
                     float a[VEC], b[VEC];
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) { a[e] = 0.f; b[e] = 0.f; }
-                    // rounds of 8 partials: every load of a round is in flight before the first add (order 0,1,2,..)
+                    // rounds of R partials: every load of a round is in flight before the first add (order 0,1,2,..).  R follows the split
+                    // count (wave uniform): with 2 partials a round of 8 would request the last one seven times over
+                    auto sum_parts = [&](auto r_c) {
+                        constexpr int R = decltype(r_c)::value;
 #pragma unroll 1
-                    for (int s0 = 0; s0 < n_parts; s0 += 8) {
-                        float4 va[8][VEC / 4], vb[8][VEC / 4];
+                        for (int s0 = 0; s0 < n_parts; s0 += R) {
+                            float4 va[R][VEC / 4], vb[R][VEC / 4];
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const float* pa = parts + (size_t)min(s0 + j, n_parts - 1) * part_stride + e0;
-#pragma unroll
-                            for (int e = 0; e < VEC / 4; ++e) {
-                                va[j][e] = *reinterpret_cast<const float4*>(pa + 4 * e);
-                                vb[j][e] = *reinterpret_cast<const float4*>(pa + half + 4 * e);
-                            }
-                        }
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            if (s0 + j < n_parts) {
+                            for (int j = 0; j < R; ++j) {
+                                const float* pa = parts + (size_t)min(s0 + j, n_parts - 1) * part_stride + e0;
 #pragma unroll
                                 for (int e = 0; e < VEC / 4; ++e) {
-                                    a[4 * e] += va[j][e].x; a[4 * e + 1] += va[j][e].y; a[4 * e + 2] += va[j][e].z; a[4 * e + 3] += va[j][e].w;
-                                    b[4 * e] += vb[j][e].x; b[4 * e + 1] += vb[j][e].y; b[4 * e + 2] += vb[j][e].z; b[4 * e + 3] += vb[j][e].w;
+                                    va[j][e] = *reinterpret_cast<const float4*>(pa + 4 * e);
+                                    vb[j][e] = *reinterpret_cast<const float4*>(pa + half + 4 * e);
                                 }
                             }
-                    }
+#pragma unroll
+                            for (int j = 0; j < R; ++j)
+                                if (s0 + j < n_parts) {
+#pragma unroll
+                                    for (int e = 0; e < VEC / 4; ++e) {
+                                        a[4 * e] += va[j][e].x; a[4 * e + 1] += va[j][e].y; a[4 * e + 2] += va[j][e].z; a[4 * e + 3] += va[j][e].w;
+                                        b[4 * e] += vb[j][e].x; b[4 * e + 1] += vb[j][e].y; b[4 * e + 2] += vb[j][e].z; b[4 * e + 3] += vb[j][e].w;
+                                    }
+                                }
+                        }
+                    };
+                    if (n_parts <= 2) sum_parts(std::integral_constant<int, 2>{});
+                    else if (n_parts <= 4) sum_parts(std::integral_constant<int, 4>{});
+                    else sum_parts(std::integral_constant<int, 8>{});
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) { x1[e] = Elem<T>::st(a[e]); x2[e] = Elem<T>::st(b[e]); }
                 } else {
@@ -141,14 +150,20 @@ __global__ __launch_bounds__(256) void rope_kv_append_kernel(typename Elem<T>::S
             if (tt < nt) {
                 const size_t e0 = (size_t)(t0 + tt) * row_w + (size_t)(H + Hkv + kvh) * d + d0 + d4;
                 float4 a = float4{0.f, 0.f, 0.f, 0.f};
-                for (int s0 = 0; s0 < n_parts; s0 += 8) {
-                    float4 pv[8];
+                auto sum_v = [&](auto r_c) {
+                    constexpr int R = decltype(r_c)::value;
+                    for (int s0 = 0; s0 < n_parts; s0 += R) {
+                        float4 pv[R];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) pv[j] = *reinterpret_cast<const float4*>(parts + (size_t)min(s0 + j, n_parts - 1) * part_stride + e0);
+                        for (int j = 0; j < R; ++j) pv[j] = *reinterpret_cast<const float4*>(parts + (size_t)min(s0 + j, n_parts - 1) * part_stride + e0);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (s0 + j < n_parts) { a.x += pv[j].x; a.y += pv[j].y; a.z += pv[j].z; a.w += pv[j].w; }
-                }
+                        for (int j = 0; j < R; ++j)
+                            if (s0 + j < n_parts) { a.x += pv[j].x; a.y += pv[j].y; a.z += pv[j].z; a.w += pv[j].w; }
+                    }
+                };
+                if (n_parts <= 2) sum_v(std::integral_constant<int, 2>{});
+                else if (n_parts <= 4) sum_v(std::integral_constant<int, 4>{});
+                else sum_v(std::integral_constant<int, 8>{});
                 sm[tt][d4] = Elem<T>::st(a.x); sm[tt][d4 + 1] = Elem<T>::st(a.y); sm[tt][d4 + 2] = Elem<T>::st(a.z); sm[tt][d4 + 3] = Elem<T>::st(a.w);
             }
         }

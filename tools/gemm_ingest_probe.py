@@ -1,15 +1,19 @@
-"""What the activation re-reads cost the weight-streaming GEMM: the same launches with one operand's traffic removed
-(LADE_GEMM_DBG bit 64: every activation piece re-reads one line; bit 128: every weight piece does), with and without the MFMA /
-store phases (bits 4 / 1).  Run once per LADE_GEMM_DBG value: 0, 64, 128, 5, 69, 133."""
+"""What the activation re-reads cost the weight-streaming GEMM: the 7B / 13B step's launches with the activation traffic removed
+(LADE_GEMM_DBG bit 128: every activation piece re-reads one cached line - results are then meaningless), with and without the output
+stores (bit 1) and the LDS-read / MFMA phase (bit 4).  K-tile-major weights, every launch on another layer's weights, 40 launches per hipGraph.
+Run once per LADE_GEMM_DBG value (the env is read once per process):  for d in 0 128 1 129 5 133; do LADE_GEMM_DBG=$d python tools/gemm_ingest_probe.py; done"""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from lookaheaddecoding_amd.cabi import call, dtype_code, ptr
+from lookaheaddecoding_amd import ops
 
 M = int(os.environ.get("M", "60"))
+MODEL = os.environ.get("MODEL", "7b")
+HID, INTER, QKV = {"7b": (4096, 11008, 12288), "13b": (5120, 13824, 15360)}[MODEL]
+mb = (M + 31) // 32
 
 
 def timeit(fn, reps=40, rounds=5):
@@ -32,22 +36,26 @@ def timeit(fn, reps=40, rounds=5):
 
 
 line = []
-# (name, N, K, S, bn, mb, mt, nt, epilogue): the 7B step's choices at 60 rows
-for name, N, K, S, bn, mb, mt, nt, epi in (("qkv", 12288, 4096, 4, 192, 2, 2, 0, 0), ("o", 4096, 4096, 8, 128, 2, 1, 0, 0),
-                                           ("gate_up(fused)", 22016, 4096, 1, 96, 2, 1, 1, 1), ("down", 4096, 11008, 8, 128, 2, 1, 0, 0)):
+# (name, N, K, S, bn, mt, nt, ring): the in-step tuner's usual choices
+cfgs = {60: (("qkv", QKV, HID, 2, 96, 1, 1, 0), ("o", HID, HID, 4, 64, 1, 1, 0), ("gate_up", 2 * INTER, HID, 1, 96, 1, 1, 8), ("down", HID, INTER, 4, 64, 1, 1, 0)),
+        120: (("qkv", QKV, HID, 3, 192, 1, 0, 3), ("o", HID, HID, 3, 64, 1, 0, 3), ("gate_up", 2 * INTER, HID, 1, 128, 2, 1, 3), ("down", HID, INTER, 6, 128, 2, 0, 5))}[M if M in (60, 120) else 60]
+for name, N, K, S, bn, mt, nt, ring in cfgs:
     a = torch.randn(M, K, device="cuda").bfloat16()
-    ws = [torch.randn(N, K, device="cuda").bfloat16() * 0.02 for _ in range(max(2, int(600e6 / (N * K * 2))))]
-    out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-    part = torch.empty(max(S, 2), M, N, dtype=torch.float32, device="cuda")
+    n_w = max(3, int(700e6 / (N * K * 2)))
+    kts = [ops.to_ktile((torch.randn(N, K, device="cuda") * 0.02).bfloat16()) for _ in range(n_w)]
+    part = torch.empty(16 * 128 * N, dtype=torch.float32, device="cuda")
+    act = torch.empty(M, N // 2, dtype=torch.bfloat16, device="cuda")
     i = [0]
 
-    def mine():
-        i[0] = (i[0] + 1) % len(ws)
-        call("lade_gemm_skinny", ptr(a), a.stride(0), ptr(ws[i[0]]), ws[i[0]].stride(0), ptr(out) if S == 1 else None, out.stride(0) if S == 1 else 0,
-             ptr(part), M, N, K, S, bn, mb, mt, nt, 0, epi, dtype_code(a))
-
-    t = timeit(mine)
-    wg = -(-N // bn) * S
-    a_mb = wg * 64 * (K / S) * 2 / 1e6
-    line.append(f"{name} {t:6.2f} us (W {N * K * 2 / 1e6:.0f} MB, A re-reads {a_mb:.0f} MB, {wg} WGs)")
-print(f"LADE_GEMM_DBG={os.environ.get('LADE_GEMM_DBG', '0'):>3s} M={M}: " + " | ".join(line), flush=True)
+    def run():
+        i[0] = (i[0] + 1) % n_w
+        if S == 1:
+            ops.gemm_swiglu(a, kts[i[0]], act, bn, mb, mt, nt, ring)
+        else:
+            ops.gemm_parts(a, kts[i[0]], part, S, bn, mb, mt, nt, ring)
+    t = timeit(run)
+    n_wg = ((N + bn - 1) // bn) * S
+    line.append(f"{name} {t:6.2f} us ({N * K * 2 / 1e6 / t:4.2f} TB/s of W; A re-reads {n_wg * M * (K // S) * 2 / 1e6:.0f} MB over {n_wg} WGs)")
+    del kts
+    torch.cuda.empty_cache()
+print(f"LADE_GEMM_DBG={os.environ.get('LADE_GEMM_DBG', '0'):>3s} {MODEL} M={M}: " + " | ".join(line), flush=True)
