@@ -106,7 +106,7 @@ def pmc_traffic(cfg, T, P, n_splits):
     attention + combine kernels.  Only reported when a profiled launch has THIS run's shape - heads, KV heads, head size, T, split
     count, and the cache length within 128 keys; returns (bytes, source file)."""
     H, Hkv, d = cfg["heads"], cfg["kv_heads"], cfg["head_dim"]
-    for name in ("r3_attn_pmc.json", "r2_attn_pmc.json"):
+    for name in ("r4_attn_pmc.json", "r3_attn_pmc.json", "r2_attn_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as f:
@@ -172,7 +172,7 @@ def cpu_baseline(c, cfg_full, prompt_len, n_steps, allow_full=True):
     """the reference's CPU greedy path on this box's cores.  The reference itself cannot travel here; its
     port (oracle/lade_oracle.py, pinned to reference-generated traces) is timed on steady lookahead steps at the bench's own prompt
     length.  FULL depth when the fp32 model fits the host's memory and the time budget (the 7B shape: 27 GB, ~2 s / step);
-    otherwise (13B / 70B shapes) the same widths at 2 and 4 layers, the per-layer time extrapolated to the full depth."""
+    otherwise (13B / 70B shapes) the same widths at 4 and 8 layers, the per-layer time extrapolated to the full depth."""
     O = _oracle()
     from lookaheaddecoding_amd.weights import make_config, weight_shapes
     cores = host_cores()
@@ -193,12 +193,12 @@ def cpu_baseline(c, cfg_full, prompt_len, n_steps, allow_full=True):
                   f"KV cache of {prompt_len} synthetic rows, {n_steps} steady steps of T={T} tokens after one untimed step, W={W} N={N} G={G}, S=1.0 (cold regime: 1 token/step)")
     else:
         t = {}
-        for Ls in (2, 4):
+        for Ls in (4, 8):
             t[Ls], T, _ = _cpu_steady_step(O, c, make_config(cfg_full, layers=Ls), prompt_len, max(2, n_steps - 1))
-        per_layer = max((t[4] - t[2]) / 2, 1e-9)
-        fixed = max(t[2] - 2 * per_layer, 0.0)
+        per_layer = max((t[8] - t[4]) / 4, 1e-9)
+        fixed = max(t[4] - 4 * per_layer, 0.0)
         step_s = fixed + cfg_full["layers"] * per_layer
-        sample = (f"{head}, {cores} threads; the full widths at 2 and 4 layers (steady steps {t[2]:.2f} s and {t[4]:.2f} s -> {per_layer * 1e3:.0f} ms per layer, "
+        sample = (f"{head}, {cores} threads; the full widths at 4 and 8 layers (steady steps {t[4]:.2f} s and {t[8]:.2f} s -> {per_layer * 1e3:.0f} ms per layer, "
                   f"{fixed * 1e3:.0f} ms of lm_head / embedding) scaled to {cfg_full['layers']} layers = {step_s:.2f} s/step (full depth, {n_param * 4 / 1e9:.0f} GB in fp32, "
                   f"is beyond the bench's memory / time budget), KV cache of {prompt_len} synthetic rows, steady steps of T={T} tokens, W={W} N={N} G={G}, "
                   f"S=1.0 (cold regime: 1 token/step)")

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.."
 ROOT=$PWD
 OUTJ=$1
 P=${2:-2190}
-RAW=$ROOT/gpurun_out/r3/pmc
+RAW=${RAW_DIR:-$ROOT/gpurun_out/r4p/pmc}
 mkdir -p $RAW
 export TMPDIR=/tmp
 pass() {   # label, counters, command...
