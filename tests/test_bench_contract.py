@@ -7,7 +7,7 @@ from conftest import ROOT
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    with open(os.path.join(ROOT, "profiles", "r3_bench.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r4_bench.json")) as f:
         line = [l for l in f.read().splitlines() if l.strip().startswith("{")][-1]
     d = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
@@ -24,6 +24,17 @@ def test_committed_bench_line_has_the_contract_fields():
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1
     assert abs(d["value"] - d["step_compression"] * 1e3 / d["ms_per_step"]) / d["value"] < 0.02      # tokens/s = S / step time
+    # round 4: the port's speed calibrated against the shim-loaded reference (oracle/cpu_calibration.json, written in the build container)
+    cal = c["calibration_vs_reference"]
+    assert cal and all(0.5 < x < 1.5 for x in cal["port_over_reference_time"]) and "calibration" in c["sample"]
+    with open(os.path.join(ROOT, "oracle", "cpu_calibration.json")) as f:
+        assert [x["port_over_reference_time"] for x in json.load(f)["cases"]] == cal["port_over_reference_time"]
+    # round 4: the regime the reference publishes (S ~ 1.6-2.3) and the host's share of a step
+    m = d["mid_regime"]
+    assert m["unit"] == "tokens/s" and abs(m["speedup_vs_plain"] - m["step_compression"] * m["plain_ms_per_token"] / m["ms_per_step"]) < 0.01
+    assert m["in_published_range"] == (1.6 <= m["step_compression"] <= 2.3) and "of the first 64 generated tokens" in m["equals_plain_greedy_for"]
+    g = d["step_gpu_only"]
+    assert g["valid"] and abs(g["host_turnaround_us_per_step"] - (d["ms_per_step"] - g["ms_per_step_back_to_back"]) * 1e3) < 1.0 and abs(g["host_turnaround_us_per_step"]) < 30
 
 
 def test_step_stream_bytes_model_and_the_committed_figure():
@@ -38,7 +49,7 @@ def test_step_stream_bytes_model_and_the_committed_figure():
     kv = 2 * 32 * 2091 * 128 * 2
     assert bench.step_stream_bytes(cfg, 2091, 1) == 32 * (per_layer + kv) + 32000 * 4096 * 2
     assert bench.step_stream_bytes(cfg, 2091, 0) == 32 * (per_layer + kv)
-    with open(os.path.join(ROOT, "profiles", "r3_bench.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r4_bench.json")) as f:
         d = json.loads([l for l in f.read().splitlines() if l.strip().startswith("{")][-1])
     s = d["step_stream"]
     assert s["bound"] == "hbm" and s["unit"] == "GB/s" and s["peak"] == 8000.0
@@ -49,7 +60,7 @@ def test_step_stream_bytes_model_and_the_committed_figure():
 def test_projections_object_of_the_committed_line_is_consistent():
     """bench.py's `projections` (what the engine's autotune timed for the kernels it chose): weight bytes of the 7B shape, TB/s = bytes / time,
     the layer sum, and the layout the line says the GEMMs stream"""
-    with open(os.path.join(ROOT, "profiles", "r3_bench_projections.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r4_bench.json")) as f:
         d = json.loads([l for l in f.read().splitlines() if l.strip().startswith("{")][-1])
     p = d["projections"]
     assert p["row_class"] == 64 and p["weight_layout"] == "k-tile-major" and "K-tile-major" in d["config"]["weight_layout"]
@@ -58,6 +69,12 @@ def test_projections_object_of_the_committed_line_is_consistent():
     for n, mb in want_mb.items():
         e = p[n]
         assert abs(e["weight_mb"] - mb) < 0.1 and abs(e["tb_per_s"] - mb / e["us"]) < 0.02 and abs(e["frac_of_8_tb_per_s"] - e["tb_per_s"] / 8.0) < 2e-3
-        assert e["kernel"] == "library" or len(e["kernel"]) == 5
+        assert e["kernel"] == "library" or len(e["kernel"]) == 6          # (mb, bn, n_split, mt, nt, ring)
         tot += e["us"]
     assert abs(p["layer_sum_us"] - tot) < 0.05 and 0.3 < p["layer_tb_per_s"] / 8.0 < 1.0
+    # the decisions re-taken inside a step: per projection both choices and their per-layer times in the 8-layer probe
+    t = p["in_step_tuning"]
+    assert set(t) == set(want_mb)
+    for n, e in t.items():
+        assert e["ms_per_layer_in_step_choice"] <= e["ms_per_layer_isolated_choice"] + 1e-9 and e["candidates"] >= 2
+        assert e["in_step_choice"] == p[n]["kernel"]
