@@ -21,7 +21,8 @@
  *                            lade/models/modeling_llama.py:321-346, :510-516
  *   lade_kv_commit           lade/decoding.py:1154-1163 (greedy) / :582-590 (sample)
  *   lade_build_inputs        lade/models/modeling_llama.py:1463-1511 (ids / position_ids assembly)
- *   lade_argmax_rows         torch.argmax(outputs.*_logits, dim=-1)  lade/decoding.py:1021,1041,1052,1072,1102
+ *   lade_argmax_rows / lade_argmax_pairs   torch.argmax(outputs.*_logits, dim=-1)  lade/decoding.py:1021,1041,1052,1072,1102
+ *                            (pairs: on what the lm_head GEMM's argmax epilogue leaves instead of the logits)
  *   lade_verify_greedy       lade/decoding.py:1071-1084
  *   lade_pool_insert_window  update_token_map             lade/decoding.py:37-63
  *   lade_pool_insert_ngrams  fill_pool_with_prompt / append_new_generated_pool  lade/decoding.py:80-127
@@ -38,7 +39,7 @@
  *                            finally drawn from) / the per-candidate draft probabilities of the acceptance loop, gathered on
  *                            the device without materialising guess_probs   lade/decoding.py:484-540
  *   lade_warp_rows           temperature / top-k / top-p warpers in one launch   lade/decoding.py:375-377, :443, :488
- *   lade_rmsnorm / lade_add_rmsnorm / lade_silu_mul / lade_gather_rows   LlamaRMSNorm (+ residual add), SwiGLU,
+ *   lade_rmsnorm / lade_embed_rmsnorm / lade_add_rmsnorm / lade_silu_mul / lade_gather_rows   LlamaRMSNorm (+ residual add), SwiGLU,
  *                            embedding / logits-row gather around the GEMMs
  *                            lade/models/modeling_llama.py:222-227, :360-380, :1164 ("next" row)
  *   lade_gemm_skinny / lade_gemm_skinny_kt / lade_weight_to_ktile / lade_weight_from_ktile / lade_splitk_reduce   the nn.Linear projections of the step at M = T <= 128 rows
@@ -201,6 +202,10 @@ int lade_build_inputs(const int32_t* in_ids, const int32_t* in_pos, int32_t n_in
 int lade_argmax_rows(const void* logits, int64_t ld, int32_t rows, int32_t V, int32_t dtype, int32_t* out,
                      void* stream);
 
+/* out[r] = column of the best of row r's n_blocks {value, column} pairs (lade_gemm_skinny, epilogue 2): the same ids lade_argmax_rows
+ * returns on the materialised logits (first index wins ties). */
+int lade_argmax_pairs(const float* pairs, int32_t rows, int32_t n_blocks, int32_t* out, void* stream);
+
 /* out3 = {max_hit, max_hit_idx}, hits[gs]; g may also come from ctl[LADE_CTL_G] when dyn != 0 */
 int lade_verify_greedy(const int32_t* first_guess, const int32_t* guess, const int32_t* guess_argmax, int32_t g,
                        int32_t gs, int32_t* out2, int32_t* hits, void* stream);
@@ -311,6 +316,10 @@ int lade_warp_rows(const void* logits, int64_t ld, int32_t rows, int32_t V, int3
 /* y = weight * (x * rsqrt(mean(x^2) + eps)) with the reference's rounding (fp32 norm, cast, then * weight) */
 int lade_rmsnorm(const void* x, const void* weight, void* y, int32_t rows, int32_t hidden, float eps, int32_t dtype,
                  void* stream);
+/* the embedding lookup of a step (lade/models/modeling_llama.py:1413 `embed_tokens(input_ids)`) fused with the first layer's input norm
+ * (:857): x[r] = table[ids[r]] (ids clamped to the table), y[r] = rmsnorm(x[r]) - one launch instead of a row gather and a norm */
+int lade_embed_rmsnorm(const void* table, int32_t table_rows, const int32_t* ids, void* x, const void* weight, void* y, int32_t rows,
+                       int32_t hidden, float eps, int32_t dtype, void* stream);
 /* y = x + r (residual add) fused with the norm of the sum: x <- x + r ; y = rmsnorm(x) */
 int lade_add_rmsnorm(void* x, const void* r, const void* weight, void* y, int32_t rows, int32_t hidden, float eps,
                      int32_t dtype, void* stream);
@@ -342,7 +351,10 @@ int lade_gather_rows(const void* src, const int32_t* idx, void* dst, int32_t row
  * mb = 8, nt = 2 | 4 is a compute-shaped 256 x 256 tile on a double buffer).
  * epilogue (n_split == 1 only): 0 = none; 1 = SwiGLU - W is the fused gate/up weight in the 16-row interleaved order of
  * lade_silu_mul's layout 1 and C is [M][N/2] = silu(gate) * up (the SwiGLU kernel and the fp32 partials of a split-K
- * gate/up GEMM disappear from the step). */
+ * gate/up GEMM disappear from the step); 2 = row argmax (the lm_head of a greedy step, lade/models/modeling_llama.py:1541-1544 +
+ * torch.argmax at lade/decoding.py:1021): C is not written (may be null), Cpart receives one {float value, int32 column} pair per row
+ * and column block - Cpart[(m * ceil(N / bn) + block) * 2] - the value rounded to the model dtype, the lowest column among equal
+ * values; lade_argmax_pairs merges a row's pairs.  The [rows, V] logits never reach HBM. */
 int lade_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, float* Cpart,
                      int32_t M, int32_t N, int32_t K, int32_t n_split, int32_t bn, int32_t mb, int32_t mt, int32_t nt,
                      int32_t ring, int32_t epilogue, int32_t dtype, void* stream);

@@ -65,6 +65,7 @@ SIGNATURES = {
     "lade_kv_commit": [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp],
     "lade_build_inputs": [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp],
     "lade_argmax_rows": [_vp, _i64, _i32, _i32, _i32, _vp, _vp],
+    "lade_argmax_pairs": [_vp, _i32, _i32, _vp, _vp],
     "lade_verify_greedy": [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp],
     "lade_pool_insert_window": [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _vp],
     "lade_pool_insert_ngrams": [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp],
@@ -86,6 +87,7 @@ SIGNATURES = {
     "lade_softmax_gather": [_vp, _i64, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "lade_warp_rows": [_vp, _i64, _i32, _i32, _i32, _f32, _i32, _f32, _i32, _vp, _vp],
     "lade_rmsnorm": [_vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp],
+    "lade_embed_rmsnorm": [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp],
     "lade_add_rmsnorm": [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp],
     "lade_add_rmsnorm_rows": [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp],
     "lade_silu_mul": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],

@@ -64,12 +64,12 @@ static int gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, b
                        int32_t epilogue, int32_t dtype, void* stream) {
     LADE_REQUIRE(ring == 0 || (ring >= 2 && ring <= 8), LADE_E_ARG, "lade_gemm_skinny: ring=%d (0 = default, 2..8 stages)", ring);
     LADE_REQUIRE(ring != 7, LADE_E_ARG, "lade_gemm_skinny: no loop is compiled for a ring of 7 stages (2, 3, 4, 5, 6, 8 are)");
-    LADE_REQUIRE(epilogue == 0 || (epilogue == 1 && n_split == 1 && N % 32 == 0 && C != nullptr), LADE_E_ARG,
-                 "lade_gemm_skinny: epilogue=%d needs n_split == 1, N %% 32 == 0 and an output matrix", epilogue);
+    LADE_REQUIRE(epilogue == 0 || (epilogue == 1 && n_split == 1 && N % 32 == 0 && C != nullptr) || (epilogue == 2 && n_split == 1 && Cpart != nullptr), LADE_E_ARG,
+                 "lade_gemm_skinny: epilogue=%d needs n_split == 1 and N %% 32 == 0 + an output matrix (1) or the pair buffer in Cpart (2)", epilogue);
     LADE_REQUIRE(A && W && M > 0 && N > 0 && K > 0 && n_split >= 1, LADE_E_ARG, "lade_gemm_skinny: M=%d N=%d K=%d split=%d", M, N, K, n_split);
     LADE_REQUIRE(K % G_BK == 0 && lda % 8 == 0 && ldw % 8 == 0 && N % 8 == 0, LADE_E_ARG,
                  "lade_gemm_skinny: K=%d must be a multiple of %d, strides / N multiples of 8", K, G_BK);
-    LADE_REQUIRE(n_split == 1 ? (C != nullptr && ldc % (epilogue ? 4 : 8) == 0) : (Cpart != nullptr), LADE_E_ARG, "lade_gemm_skinny: missing output buffer");
+    LADE_REQUIRE(epilogue == 2 || (n_split == 1 ? (C != nullptr && ldc % (epilogue ? 4 : 8) == 0) : (Cpart != nullptr)), LADE_E_ARG, "lade_gemm_skinny: missing output buffer");
     LADE_REQUIRE(dtype == LADE_BF16 || dtype == LADE_F16, LADE_E_DTYPE, "lade_gemm_skinny: dtype=%d", dtype);
     if (mb == 0) mb = M <= 32 ? 1 : (M <= 64 ? 2 : (M <= 96 ? 3 : (M <= 128 ? 4 : (M <= 192 ? 6 : 8))));
     if (mt == 0) mt = mb <= 4 ? 1 : mb / 2;

@@ -19,7 +19,8 @@ struct GemmK {
     int M, N, K, n_split;
     int n_stage;           // LDS ring depth of this launch (0: the shape's default)
     int dbg;               // ablation switches for tools/gemm_ablate.py (LADE_GEMM_DBG): 1 = no output stores, 4 = no LDS reads / MFMA
-    int epi;               // n_split == 1 only: 0 = C = A.W^T;  1 = SwiGLU over interleaved gate / up rows, C is [M][N/2]
+    int epi;               // n_split == 1 only: 0 = C = A.W^T;  1 = SwiGLU over interleaved gate / up rows, C is [M][N/2];
+                           // 2 = row argmax: no C, Cpart holds one (value, column) pair per row and column block
 };
 
 // launch the kernel built for this wave grid (mw x ng waves compute, mt x nt MFMA tiles each); -1 when it is not in the shape table

@@ -224,6 +224,51 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
                 }
             }
         }
+    } else if (g.n_split == 1 && g.epi == 2) {
+        // Row argmax in the epilogue (greedy steps: `torch.argmax(logits)` of lade/decoding.py:1021 on the rows of
+        // modeling_llama.py:1541-1544): the [rows, V] logits never reach HBM.  Per activation row this work-group's best (value, column)
+        // over its BN columns, the value rounded to the model dtype first (the logits the reference compares are 16-bit), the LOWEST
+        // column among equal values (torch.argmax; lade_argmax_rows) - written as a pair to Cpart[(m * gridDim.x + blockIdx.x) * 2],
+        // merged across the column blocks by lade_argmax_pairs.  A lane holds the columns 8 g4 + 4 hi + e of tile j in ascending order.
+        float* sv = reinterpret_cast<float*>(smem);
+        int* si = reinterpret_cast<int*>(smem + NG * BM * 4);
+        if (computes)
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            float best = -INFINITY;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int n = n0 + (ng * NT + j) * 32 + 8 * g4 + 4 * hi + e;
+                        const float v = g_rnd<T>(acc[a][j][4 * g4 + e]);
+                        if (n < g.N && (v > best || bi == 0x7fffffff)) { best = v; bi = n; }
+                    }
+            const float ob = __shfl_xor(best, 32);
+            const int oi = __shfl_xor(bi, 32);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            if (hi == 0) {
+                sv[ng * BM + (mw * MT + a) * 32 + ql] = best;
+                si[ng * BM + (mw * MT + a) * 32 + ql] = bi;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        g_barrier();
+        if (tid < BM && m0 + tid < g.M) {
+            float best = sv[tid];
+            int bi = si[tid];
+#pragma unroll
+            for (int q = 1; q < NG; ++q) {
+                const float ob = sv[q * BM + tid];
+                const int oi = si[q * BM + tid];
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            float* dst = g.Cpart + ((size_t)(m0 + tid) * gridDim.x + blockIdx.x) * 2;
+            *reinterpret_cast<float2*>(dst) = float2{best, __int_as_float(bi)};
+        }
     } else if (g.n_split == 1) {
         // stage [BM][BN] in the model dtype, then whole-row 16-byte stores
         constexpr int RS = BN * 2 + 16;
@@ -316,7 +361,7 @@ static int launch_gemm(const GemmK& g0, hipStream_t st) {
                  "lade_gemm_skinny: a ring of %d stages of %d + %d rows does not fit the %d KB of LDS", g.n_stage, BN, BM, G_LDS_MAX / 1024);
     // the epilogue stages the [BM][BN] tile through the LDS (model dtype without split-K, fp32 partials with it); an fp32 tile larger
     // than the LDS (the 256 x 256 shape) is stored straight from the accumulators instead
-    size_t stg = g.n_split == 1 ? (g.epi == 1 ? 0 : (size_t)BM * (BN * 2 + 16)) : (size_t)BM * (BN * 4 + 16);
+    size_t stg = g.n_split == 1 ? (g.epi == 1 ? 0 : (g.epi == 2 ? (size_t)NG * BM * 8 : (size_t)BM * (BN * 2 + 16))) : (size_t)BM * (BN * 4 + 16);
     if (g.n_split > 1 && stg > (size_t)G_LDS_MAX) { g.dbg |= 32; stg = 0; }
     const size_t ring = g.n_stage * STAGE, lds = ring > stg ? ring : stg;
     static_assert((size_t)BM * (BN * 2 + 16) <= (size_t)G_LDS_MAX, "model-dtype staging must fit the LDS");

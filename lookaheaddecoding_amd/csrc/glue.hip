@@ -155,12 +155,16 @@ __global__ __launch_bounds__(BT) void rmsnorm_kernel(typename St<T>::S* x, const
     float v[CH][N];
     u32x4 wv[CH];
     float ss = 0.f;
+    // without ADD, `r` may name a row table (the embedding matrix, lade_embed_rmsnorm): the block's input row is r[sel[blockIdx.x]] and
+    // is also copied to x[blockIdx.x] - the step's embedding gather and its first norm in one launch (modeling_llama.py:1413, :857)
+    const typename St<T>::S* xin = (!ADD && r) ? r : x;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         const int i = threadIdx.x + c * BT;
         if (i < nvec) {
             wv[c] = *reinterpret_cast<const u32x4*>(w + (size_t)i * N);
-            const u32x4 xr = *reinterpret_cast<const u32x4*>(x + base + (size_t)i * N);      // used only after the partial loads are in flight
+            const u32x4 xr = *reinterpret_cast<const u32x4*>(xin + base + (size_t)i * N);      // used only after the partial loads are in flight
+            if (!ADD && r) *reinterpret_cast<u32x4*>(x + obase + (size_t)i * N) = xr;
             float rr[N];
             if (ADD) {
                 if (parts) load_parts<T, N>(parts, n_parts, part_stride, base + (size_t)i * N, rr);
@@ -364,6 +368,14 @@ extern "C" int lade_rmsnorm(const void* x, const void* weight, void* y, int32_t 
     if (rows == 0) return LADE_OK;
     hipStream_t st = (hipStream_t)stream;
     return launch_rmsnorm<false>((void*)x, nullptr, weight, y, rows, hidden, eps, dtype, st);
+}
+
+extern "C" int lade_embed_rmsnorm(const void* table, int32_t table_rows, const int32_t* ids, void* x, const void* weight, void* y, int32_t rows,
+                                  int32_t hidden, float eps, int32_t dtype, void* stream) {
+    LADE_REQUIRE(table && ids && x && weight && y && rows >= 0 && hidden > 0 && table_rows > 0 && x != table, LADE_E_ARG,
+                 "lade_embed_rmsnorm: rows=%d hidden=%d table_rows=%d", rows, hidden, table_rows);
+    if (rows == 0) return LADE_OK;
+    return launch_rmsnorm<false>(x, table, weight, y, rows, hidden, eps, dtype, (hipStream_t)stream, nullptr, 0, 0, ids, table_rows);
 }
 
 extern "C" int lade_add_rmsnorm(void* x, const void* r, const void* weight, void* y, int32_t rows, int32_t hidden, float eps, int32_t dtype, void* stream) {

@@ -339,6 +339,33 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(const void* logits, i
     }
 }
 
+// merge of the (value, column) pairs the lm_head GEMM's argmax epilogue leaves per row and column block (gemm_kernel.hpp, epi == 2):
+// one wave per row, every pair of the row requested before the first compare; the lowest column wins among equal values
+__global__ __launch_bounds__(64) void argmax_pairs_kernel(const float2* pairs, int nb, int32_t* out) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    const float2* p = pairs + (size_t)row * nb;
+    constexpr int R = 8;                                   // 512 column blocks per pass (V = 32000 at 96 columns per block: 334)
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int b0 = 0; b0 < nb; b0 += 64 * R) {
+        float2 v[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) v[k] = p[min(b0 + k * 64 + lane, nb - 1)];
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+            if (b0 + k * 64 + lane < nb) {
+                const int oi = __float_as_int(v[k].y);
+                if (v[k].x > best || (v[k].x == best && oi < bi) || bi == 0x7fffffff) { best = v[k].x; bi = oi; }
+            }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) out[row] = bi;
+}
+
 // ---- fused post-step of one single-rank greedy step ------------------------------------------------
 // am = [out row | n_inp inp rows | cand_rows guess rows] argmax ids.  See include/lade_hip.h.
 // phase 0 = prefill step, 1 = window-fill step, 2 = steady step (lade/decoding.py:1038-1130).
@@ -676,6 +703,13 @@ extern "C" int lade_argmax_rows(const void* logits, int64_t ld, int32_t rows, in
         default: LADE_REQUIRE(false, LADE_E_DTYPE, "lade_argmax_rows: dtype=%d", dtype);
     }
     return check_launch("lade_argmax_rows");
+}
+
+extern "C" int lade_argmax_pairs(const float* pairs, int32_t rows, int32_t n_blocks, int32_t* out, void* stream) {
+    LADE_REQUIRE(pairs && out && rows >= 0 && n_blocks > 0 && ((size_t)pairs & 7) == 0, LADE_E_ARG, "lade_argmax_pairs: rows=%d n_blocks=%d", rows, n_blocks);
+    if (rows == 0) return LADE_OK;
+    hipLaunchKernelGGL(argmax_pairs_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, (const float2*)pairs, n_blocks, out);
+    return check_launch("lade_argmax_pairs");
 }
 
 extern "C" uint32_t lade_record_seal(const uint32_t* rec, uint32_t step_no) { return rec ? seal_words(rec, step_no) : 0u; }

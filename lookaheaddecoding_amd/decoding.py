@@ -190,10 +190,13 @@ class LookaheadDecoder:
         T = mask.T
         call("lade_build_inputs", None, None, 1, ptr(st.window), st.wcap, ptr(st.ctl), N - 2, 0, -1, ptr(st.guess), -1, gs, cand_rows,
              ptr(st.ids), ptr(st.pos), None, 0, 1)
+        # greedy steps take the row argmax inside the lm_head GEMM (argmax_out: the logits are never materialised); the sampling verify
+        # needs the rows themselves
         logits = e.forward(st.ids, st.pos, mask, self._graph_sel[gcap], 1 + W + cand_rows, dyn_P=st.ctl, n_splits=self._graph_splits[gcap],
-                           ntk_pad=(st.ctl[CTL_G:CTL_G + 1], gcap, gs))      # (dynamic-NTK RoPE only: the padded candidate slots are not sequence length)
-        ops.argmax_rows(logits, out=st.am)
+                           ntk_pad=(st.ctl[CTL_G:CTL_G + 1], gcap, gs),      # (dynamic-NTK RoPE only: the padded candidate slots are not sequence length)
+                           argmax_out=None if forward_only else st.am)
         if forward_only:
+            ops.argmax_rows(logits, out=st.am)
             return logits.float()                                   # logits.float(), modeling_llama.py:1544
         # LADE_POLL (default on): the post-step stores the sealed record straight into the pinned host buffer and the host polls for it;
         # otherwise a copy node carries it and the host synchronises the stream
@@ -300,8 +303,9 @@ class LookaheadDecoder:
             # rows whose logits are needed: out row, last level's rows, candidate rows (:1578-1606)
             rows = [n_input - 1] + list(range(T - cand_rows - n_inp, T - cand_rows)) + list(range(T - cand_rows, T))
             n_sel = self._set_sel(rows)
-            logits = e.forward(st.ids, st.pos, mask, st.sel, n_sel)
-        ops.argmax_rows(logits, out=st.am)
+            logits = e.forward(st.ids, st.pos, mask, st.sel, n_sel, argmax_out=st.am)
+        if logits is not None:                       # the prefill step returns its logits, a decode step has taken the argmax already
+            ops.argmax_rows(logits, out=st.am)
         call("lade_greedy_post_step", ptr(st.ctl), ptr(st.window), st.wcap, ptr(st.pool_tok), ptr(st.pool_cnt), st.V, W, N, G,
              ptr(st.am), n_inp, ptr(st.guess), T, cand_rows, phase, int(self.pool_from_prompt), ptr(st.tail), self.eos, None, None, ptr(st.record), None)
         ops.kv_commit(e.kv, 0, 0, 0, ctl=st.ctl)

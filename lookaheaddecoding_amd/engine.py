@@ -735,10 +735,13 @@ class StepEngine:
     # ---- one forward -----------------------------------------------------------------------------
     @_on_device
     def forward(self, ids: torch.Tensor, pos: torch.Tensor, mask: StepMask, sel_rows: torch.Tensor, n_sel: int,
-                dyn_P: Optional[torch.Tensor] = None, n_splits: Optional[int] = None, rope_len: int = 0, ntk_pad=None) -> torch.Tensor:
+                dyn_P: Optional[torch.Tensor] = None, n_splits: Optional[int] = None, rope_len: int = 0, ntk_pad=None,
+                argmax_out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
         """ids/pos: device int32 [>=T]; mask describes the step; sel_rows: device int32 [n_sel] rows whose
         logits are needed.  Appends the T new K/V rows at P..P+T and returns logits [n_sel, V] (model dtype,
-        as `self.lm_head(hidden_states)` does at lade/models/modeling_llama.py:1541)."""
+        as `self.lm_head(hidden_states)` does at lade/models/modeling_llama.py:1541).
+        argmax_out (device int32 [>= n_sel], greedy steps): the row argmax of those logits is written there and None is returned - on
+        the hand-written lm_head GEMM the argmax runs in its epilogue and the logits are never materialised."""
         T, P = mask.T, mask.P                     # with dyn_P the kernels read P from the device (mask.P is then 0)
         if T > self.max_T or P + T > self.S_max:
             raise cabi.LadeHipError(f"step of T={T} tokens at P={P} exceeds the engine limits (max_T={self.max_T}, S_max={self.S_max})")
@@ -757,12 +760,16 @@ class StepEngine:
             if mclass not in self._refined:          # once per row class: the four decisions re-taken INSIDE a step - BEFORE this call touches a workspace
                 self._refine_in_step(mclass)
                 cfg_qkv, cfg_o, cfg_gu, cfg_d = (self.gemm_cfg[(n, mclass)] for n in self.LAYER_GEMMS)
-        ops.gather_rows(self.embed, ids, out=x, rows=T)
+        fuse_embed = os.environ.get("LADE_FUSE_TAIL", "1") != "0"      # embedding lookup inside the first layer's input norm (one launch less)
+        if not (fuse_embed and self.layers):
+            ops.gather_rows(self.embed, ids, out=x, rows=T)
         rpos, rcos, rsin = (pos, self.cos, self.sin) if self._ntk is None else self._ntk_rows(pos, T, P, dyn_P, rope_len, ntk_pad)
         part = self.ws_part if fused else None
         r_parts = 0                     # > 0: the pending residual branch lives in `part` as that many split-K partials
         for li, lw in enumerate(self.layers):
-            if li == 0:
+            if li == 0 and fuse_embed:
+                ops.embed_rmsnorm(self.embed, ids, x, lw["ln1"], self.eps, h, T)
+            elif li == 0:
                 ops.rmsnorm(x, lw["ln1"], self.eps, out=h)
             elif r_parts:
                 ops.add_rmsnorm_parts(x, part, r_parts, lw["ln1"], self.eps, out=h)   # x += mlp(prev); h = norm(x)
@@ -821,11 +828,21 @@ class StepEngine:
         else:
             hn = ops.add_rmsnorm_rows(x, sel_rows, n_sel, self.norm_w, self.eps, r=r)
         cfg_lm = self._tune("lm_head", n_sel) if (self.custom_gemm and n_sel <= self.ROW_CLASSES[-1] and self.V % 8 == 0) else None
+        w_lm = self._lm_kt if self._lm_kt is not None else self._lm_head
+        if cfg_lm and argmax_out is not None and n_sel <= 128 and os.environ.get("LADE_FUSE_TAIL", "1") != "0":
+            nb = (self.V + cfg_lm[1] - 1) // cfg_lm[1]
+            pairs = torch.empty(n_sel * nb * 2, dtype=torch.float32, device=self.device)
+            ops.gemm_argmax(hn, w_lm, argmax_out, pairs, bn=cfg_lm[1], mb=cfg_lm[0], mt=cfg_lm[3], nt=cfg_lm[4], ring=cfg_lm[5])
+            return None
         if cfg_lm:
             logits = torch.empty(n_sel, self.V, dtype=self.dtype, device=self.device)
-            return ops.gemm_skinny(hn, self._lm_kt if self._lm_kt is not None else self._lm_head, out=logits, n_split=1,
-                                   bn=cfg_lm[1], mb=cfg_lm[0], mt=cfg_lm[3], nt=cfg_lm[4], ring=cfg_lm[5])
-        return torch.matmul(hn, self._lm_head.t())
+            ops.gemm_skinny(hn, w_lm, out=logits, n_split=1, bn=cfg_lm[1], mb=cfg_lm[0], mt=cfg_lm[3], nt=cfg_lm[4], ring=cfg_lm[5])
+        else:
+            logits = torch.matmul(hn, self._lm_head.t())
+        if argmax_out is not None:
+            ops.argmax_rows(logits, out=argmax_out)
+            return None
+        return logits
 
     # ---- prefill: plain causal rows over the growing cache ---------------------------------------------
     @torch.no_grad()

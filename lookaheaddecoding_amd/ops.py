@@ -178,6 +178,13 @@ def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out: Optional[torch.Te
     return out
 
 
+def embed_rmsnorm(table: torch.Tensor, ids: torch.Tensor, x: torch.Tensor, w: torch.Tensor, eps: float, out: torch.Tensor, rows: int) -> torch.Tensor:
+    """x[r] = table[ids[r]]; out[r] = rmsnorm(x[r]) for r < rows: the step's embedding lookup and its first norm in one launch."""
+    assert table.is_contiguous() and x.is_contiguous() and out.is_contiguous() and ids.dtype == torch.int32 and table.shape[1] == x.shape[1]
+    call("lade_embed_rmsnorm", ptr(table), table.shape[0], ptr(ids), ptr(x), ptr(w), ptr(out), rows, x.shape[1], eps, dtype_code(x))
+    return out
+
+
 def add_rmsnorm(x: torch.Tensor, r: torch.Tensor, w: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x += r (in place); returns rmsnorm(x)."""
     assert x.is_contiguous() and r.is_contiguous() and x.shape == r.shape
@@ -317,6 +324,22 @@ def gemm_skinny(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = 
     _gemm(a, w, ptr(out), out.stride(0), ptr(part), n_split, bn, mb, mt, nt, 0, ring)
     if n_split > 1:
         call("lade_splitk_reduce", ptr(part), ptr(out), out.stride(0), M, N, n_split, dtype_code(a))
+    return out
+
+
+def gemm_argmax(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, pairs: Optional[torch.Tensor] = None, bn: int = 128, mb: int = 0, mt: int = 0,
+                nt: int = 0, ring: int = 0) -> torch.Tensor:
+    """out[m] = argmax_n (a @ w^T)[m][n] (int32, the value compared after rounding to the model dtype, first index wins ties) without
+    materialising the product: the GEMM's epilogue leaves one (value, column) pair per row and column block in `pairs`
+    (fp32 [M, ceil(N / bn), 2]), lade_argmax_pairs merges them.  Same ids as argmax_rows(gemm_skinny(a, w))."""
+    M, N = a.shape[0], weight_rows(w)
+    assert bn in (32, 64, 96, 128, 192, 224, 256) and M <= 128, "the pair buffer is indexed by the kernel's own column-block count"
+    nb = (N + bn - 1) // bn
+    if pairs is None:
+        pairs = torch.empty(M * nb * 2, dtype=torch.float32, device=a.device)
+    assert pairs.dtype == torch.float32 and pairs.numel() >= M * nb * 2 and out.dtype == torch.int32 and out.numel() >= M
+    _gemm(a, w, None, 0, ptr(pairs), 1, bn, mb, mt, nt, 2, ring)
+    call("lade_argmax_pairs", ptr(pairs), M, nb, ptr(out))
     return out
 
 

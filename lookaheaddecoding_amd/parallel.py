@@ -215,8 +215,9 @@ class HipLPBackend:
             n_inp = ls[-1]
             rows = [n_input - 1] + list(range(T - cand_rows - n_inp, T - cand_rows)) + list(range(T - cand_rows, T))
             d._set_sel(rows)                 # cached on the device per shape: no host-to-device copy in a steady step
-            logits = e.forward(st.ids, st.pos, mask, st.sel, len(rows))
-        self.ops.argmax_rows(logits, out=st.am)
+            logits = e.forward(st.ids, st.pos, mask, st.sel, len(rows), argmax_out=st.am)
+        if logits is not None:
+            self.ops.argmax_rows(logits, out=st.am)
         am = st.am.data_ptr()
         call("lade_lp_pack", am, am + 4, n_inp, am + 4 * (1 + n_inp), g_local if phase == 2 else 0, gs, st.wcap, ptr(self.rec), self.rw, None, 0, 1)
         return self.rec
@@ -241,8 +242,7 @@ class HipLPBackend:
         mask = StepMask.from_levels(n_input, ls, cand_rows, gs, 0)
         call("lade_build_inputs", None, None, n_input, ptr(st.window), st.wcap, ptr(st.ctl), d.N - 2, c0, c1, ptr(st.guess), -1, gs, cand_rows,
              ptr(st.ids), ptr(st.pos), None, lp.rank, lp.R)
-        logits = e.forward(st.ids, st.pos, mask, sel, sel.numel(), dyn_P=st.ctl, n_splits=n_splits)
-        self.ops.argmax_rows(logits, out=st.am)
+        e.forward(st.ids, st.pos, mask, sel, sel.numel(), dyn_P=st.ctl, n_splits=n_splits, argmax_out=st.am)
         am = st.am.data_ptr()
         n_inp = ls[-1]
         call("lade_lp_pack", am, am + 4, n_inp, am + 4 * (1 + n_inp), gcap, gs, st.wcap, ptr(self.rec), self.rw, ptr(st.ctl), lp.rank, lp.R)

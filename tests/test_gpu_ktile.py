@@ -301,3 +301,93 @@ def test_weight_memory_plan_keeps_row_major_originals_while_the_budget_lasts_and
     assert not torch.equal(e3.layers[0]["wo_kt"], ops.to_ktile(e3.layers[0]["wo"]))
     e3.refresh_ktile()
     assert all(torch.equal(lw[n + "_kt"], ops.to_ktile(lw[n])) for lw in e3.layers for n in e3.LAYER_GEMMS)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_argmax_epilogue_returns_the_ids_of_argmax_over_the_materialised_logits(dtype):
+    """lade_gemm_skinny(epilogue = 2) + lade_argmax_pairs against lade_argmax_rows on the logits the same kernel writes with epilogue 0
+    (torch.argmax of lade/decoding.py:1021 on the lm_head rows of modeling_llama.py:1541): identical ids - including TIES, which the
+    16-bit rounding of the logits makes common at vocabulary width (duplicated weight rows force them here; the lowest column wins) -
+    for every column-block width and wave grid the lm_head tuner may pick, row-major and K-tile-major weights, vocabulary sizes that
+    are not a multiple of the block, 1 / 16 / 31 / 60 / 100 rows."""
+    from lookaheaddecoding_amd import ops
+    torch.manual_seed(3)
+    K = 256
+    for V in (32000, 32016, 1000):
+        w = (torch.randn(V, K, device="cuda") * 0.05).to(dtype)
+        w[V // 2] = w[7]                                   # exact ties between columns of different blocks ...
+        w[8] = w[7]                                        # ... and inside one MFMA tile
+        w[V - 1] = w[V - 3]                                # ... and in the ragged last block
+        wkt = ops.to_ktile(w)
+        for M in (1, 16, 31, 60, 100):
+            a = torch.randn(M, K, device="cuda").to(dtype)
+            a[0] = w[7].float() * 40                       # row 0's best columns are the tied ones (7, 8, V/2): 7 must win
+            mb = (M + 31) // 32
+            for bn in (64, 96, 128, 192, 256):
+                for nt in (0, 1, 2):
+                    for ww in (w, wkt):
+                        try:
+                            logits = ops.gemm_skinny(a, ww, n_split=1, bn=bn, mb=mb, nt=nt)
+                        except cabi.LadeHipError:
+                            continue                       # wave grid not in the shape table
+                        want = ops.argmax_rows(logits)
+                        got = torch.full((M,), -1, dtype=torch.int32, device="cuda")
+                        ops.gemm_argmax(a, ww, got, bn=bn, mb=mb, nt=nt)
+                        assert torch.equal(got, want), (V, M, bn, nt, ww.dim(), (got != want).nonzero().flatten().tolist()[:5])
+            assert int(want[0]) == 7
+    with pytest.raises(cabi.LadeHipError):                 # the argmax epilogue has no split-K form
+        cabi.call("lade_gemm_skinny", cabi.ptr(a), K, cabi.ptr(w), K, None, 0, cabi.ptr(torch.empty(64, device="cuda")), 1, 1000, K, 2, 128, 1, 0, 0, 0, 2,
+                  cabi.dtype_code(a))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_embed_rmsnorm_is_the_row_gather_followed_by_the_norm_bit_for_bit(dtype):
+    """lade_embed_rmsnorm (embedding lookup inside the first layer's input norm; modeling_llama.py:1413 + :857) against
+    lade_gather_rows + lade_rmsnorm: the same residual rows and the same normed rows, ids outside the table clamped like the gather."""
+    from lookaheaddecoding_amd import ops
+    torch.manual_seed(4)
+    for hidden in (64, 4096, 5120, 8192):
+        table = torch.randn(1000, hidden, device="cuda").to(dtype)
+        wn = (1 + 0.1 * torch.randn(hidden, device="cuda")).to(dtype)
+        ids = torch.randint(0, 1000, (70,), device="cuda", dtype=torch.int32)
+        ids[3], ids[4] = -5, 4000
+        for rows in (1, 60, 70):
+            x0 = torch.empty(rows, hidden, dtype=dtype, device="cuda")
+            ops.gather_rows(table, ids, out=x0, rows=rows)
+            h0 = ops.rmsnorm(x0, wn, 1e-5)
+            x1 = torch.full((rows + 1, hidden), 3.0, dtype=dtype, device="cuda")
+            h1 = torch.full((rows + 1, hidden), 3.0, dtype=dtype, device="cuda")
+            ops.embed_rmsnorm(table, ids, x1[:rows], wn, 1e-5, h1[:rows], rows)
+            assert torch.equal(x1[:rows], x0) and torch.equal(h1[:rows], h0), (hidden, rows)
+            assert bool((x1[rows] == 3.0).all()) and bool((h1[rows] == 3.0).all())          # nothing written past the rows
+
+
+def test_step_with_the_fused_tail_gives_the_argmax_and_cache_rows_of_the_unfused_step(monkeypatch):
+    """LADE_FUSE_TAIL (default on): embedding lookup inside the first norm + argmax inside the lm_head GEMM.  One engine, the same
+    step with the switch off and on: the same argmax ids as argmax_rows over the logits of the unfused step, the same appended K/V rows,
+    for a lookahead-shaped step (31 logits rows of 60), a one-token step and a step whose logits rows span 100 rows."""
+    from lookaheaddecoding_amd import ops
+    cfg = make_config("tiny-d128", max_pos=512)
+    w = {k: torch.as_tensor(v) for k, v in random_weights_numpy(cfg, seed=4, std=0.05).items()}
+    e = _engine(monkeypatch, "1", cfg, w)
+    g = torch.Generator().manual_seed(6)
+    P = 40
+    prompt = torch.randint(3, cfg["vocab"], (P,), generator=g).tolist()
+    for T, n_sel in ((60, 31), (1, 1), (120, 100)):
+        ids = torch.randint(3, cfg["vocab"], (T,), generator=g).to(torch.int32).cuda()
+        pos = (P + torch.arange(T)).to(torch.int32).cuda()
+        sel = torch.arange(T - n_sel, T, dtype=torch.int32).cuda()
+        outs = []
+        for fuse in ("0", "1"):
+            monkeypatch.setenv("LADE_FUSE_TAIL", fuse)
+            e.reset()
+            e.prefill(prompt, rows=[P - 1])
+            am = torch.full((n_sel,), -1, dtype=torch.int32, device="cuda")
+            lg = e.forward(ids, pos, ops.StepMask(T=T, P=P, is_prefill=True), sel, n_sel, argmax_out=am)
+            assert lg is None
+            outs.append((am.clone(), e.k_cache(0)[:, P:P + T].clone(), e.vt_cache(cfg["layers"] - 1)[:, :, P:P + T].clone()))
+        monkeypatch.setenv("LADE_FUSE_TAIL", "0")
+        e.reset()
+        e.prefill(prompt, rows=[P - 1])
+        want = ops.argmax_rows(e.forward(ids, pos, ops.StepMask(T=T, P=P, is_prefill=True), sel, n_sel))
+        assert torch.equal(outs[0][0], want) and all(torch.equal(x, y) for x, y in zip(*outs)), (T, n_sel)
