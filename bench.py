@@ -30,6 +30,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import random
 import socket
@@ -326,6 +327,15 @@ def worker(args):
     prefill_s = time.perf_counter() - tp0
     for _ in range(N - 2):                       # window fill: setup, untimed
         run.step()
+    if os.environ.get("LADE_BENCH_GC_FREEZE", "1") != "0":
+        # what a serving process does after start-up: the objects alive now (modules, the weights' wrappers, the prompt ...) are moved out
+        # of the collector's generations, so that a full collection triggered by the loop's own small garbage does not walk them.
+        # Without this ONE step in the first ~50 took 37-39 ms instead of 3.8 (CPython's full collection over ~10^6 long-lived objects,
+        # at a deterministic step), visible as one slow block in `spread` (profiles/r4_gc_stall.txt).  Before the warm-up steps, so that
+        # the GPU is not left idle between them and the timed region.
+        import gc
+        gc.collect()
+        gc.freeze()
     for _ in range(args.warmup):
         run.step()
     sync()
@@ -345,12 +355,19 @@ def worker(args):
     # the contract's number is the block above (exactly K steps).  Four more blocks of K steps follow for the spread: the boxes of the
     # pool drift by several per cent between consecutive runs of one binary, a single 80 ms block says nothing about that
     block_ms = [elapsed / args.steps * 1e3]
+    block_max = [None]                                            # [slowest step (ms, host clock), its index] of the blocks after the contract's
+    block_T = [round(sum(i.get("T", 0) for i in infos) / max(1, len(infos)), 1)]      # rows fed per step: a block whose steps carry candidates feeds more
     for _ in range(max(0, args.blocks - 1)):
         sync()
         tb0 = time.perf_counter()
+        binf, marks = [], [tb0]
         for _ in range(args.steps):
-            run.step()
+            binf.append(run.step())
+            marks.append(time.perf_counter())
         sync()
+        block_T.append(round(sum(i.get("T", 0) for i in binf) / max(1, len(binf)), 1))
+        gaps = [(b - a) * 1e3 for a, b in zip(marks, marks[1:])]
+        block_max.append([round(max(gaps), 3), gaps.index(max(gaps))])
         tb = time.perf_counter() - tb0
         if use_lp:
             tb_t = torch.tensor([tb], device=dev, dtype=torch.float64)
@@ -359,8 +376,9 @@ def worker(args):
         block_ms.append(tb / args.steps * 1e3)
     srt = sorted(block_ms)
     spread = {"blocks": len(block_ms), "steps_per_block": args.steps, "ms_per_step_median": round(srt[len(srt) // 2], 3), "ms_per_step_min": round(srt[0], 3),
-              "ms_per_step_max": round(srt[-1], 3), "ms_per_step_blocks": [round(x, 3) for x in block_ms],
-              "note": "block 0 is the contract's timed region (value / ms_per_step); the others follow it back to back"}
+              "ms_per_step_max": round(srt[-1], 3), "ms_per_step_blocks": [round(x, 3) for x in block_ms], "rows_per_step_blocks": block_T, "slowest_step_ms_and_index_blocks": block_max,
+              "note": "block 0 is the contract's timed region (value / ms_per_step); the others follow it back to back; a block whose steps carry "
+                      "candidates feeds more rows per step (rows_per_step_blocks) and is slower for that reason"}
     Ts = [i["T"] for i in infos if i.get("T")]
     avg_T = (sum(Ts) / len(Ts)) if Ts else float((N - 1) * W)
     P_end = run.P
@@ -499,6 +517,37 @@ def worker(args):
     # keeps repeating what it has seen, the pool hits, and S is whatever the model yields; every projection, the attention and the MLP
     # feed the logits (tests/test_gpu_parity_shapes.py: test_full_width_real_weights_bf16_with_accepted_ngrams).  The lookahead stream is
     # checked against plain greedy decoding on the same engine.
+    def greedy_check(live_prompt, gen, n_chk):
+        """Every emitted token against the PLAIN one-token step on the stream's OWN prefix (teacher forced): how many are the plain step's
+        argmax, and - where they are not - how far the emitted token's logit lies below the plain step's best, in units of the model
+        dtype's spacing at that logit.  A lookahead step computes the same logits in a batch of 60-120 rows (other split-K and KV-split
+        sums), so two logits that tie within rounding may be ranked differently: a faithful stream differs from the plain argmax only
+        where that margin is a rounding step or two - and from then on the two free-running streams are different texts, which is
+        why `equals_plain_greedy_for` alone says little on a model whose logits are nearly flat."""
+        n_chk = min(n_chk, len(gen))
+        eng.reset()
+        logits, _ = eng.prefill(list(live_prompt), [len(live_prompt) - 1])
+        one_id, one_pos, sel0 = (torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(3))
+        mant = 7 if dtype == torch.bfloat16 else 10
+        same, worst, worst_ulp = 0, 0.0, 0.0
+        Pq = len(live_prompt)
+        for j in range(n_chk):
+            row = logits[0].float()
+            top = int(ops.argmax_rows(logits)[0].item())
+            tok = int(gen[j])
+            if tok == top:
+                same += 1
+            else:
+                margin = float(row[top] - row[tok])
+                ulp = 2.0 ** (math.floor(math.log2(max(abs(float(row[top])), 1e-30))) - mant)
+                if margin / ulp > worst_ulp:
+                    worst, worst_ulp = margin, margin / ulp
+            one_id.fill_(tok)
+            one_pos.fill_(Pq)
+            logits = eng.forward(one_id, one_pos, ops.StepMask(T=1, P=Pq, is_prefill=True), sel0, 1)
+            Pq += 1
+        return {"tokens": n_chk, "plain_argmax_of_own_prefix": same, "worst_margin_where_not": round(worst, 4), "in_dtype_spacings": round(worst_ulp, 2)}
+
     def hot_live():
         # the embedding scale that makes a random model copy-biased grows with its depth and width: powers of two (exact in bf16, exactly
         # undone afterwards) are tried in turn until the model accepts n-grams (S >= 2) in a short trial
@@ -532,6 +581,7 @@ def worker(args):
         out_l = {"value": round((len(ld.tokens) - tok_l) / tl, 2), "unit": "tokens/s", "step_compression": round((len(ld.tokens) - tok_l) / args.steps, 3),
                  "ms_per_step": round(tl / args.steps * 1e3, 3), "tokens_per_step_T": round(sum(i["T"] for i in li) / len(li), 1),
                  "embedding_scale": chosen, "equals_plain_greedy_for": f"{n_same} of the first {n_chk} generated tokens",
+                 "greedy_check": greedy_check(live_prompt, gen_all, 64),
                  "how": f"live weights: embedding x{chosen:g} tied to lm_head (copy-biased random model, attention / MLP / every projection feed the logits; the "
                         "scale is the first power of two from 64 at which the model accepts n-grams), periodic prompt (period 50), POOL_FROM_PROMPT=1; S is the "
                         "model's own acceptance rate; stream compared with plain greedy on the same engine (bf16: the two may part where two logits tie within rounding)"}
@@ -582,6 +632,7 @@ def worker(args):
                  "in_published_range": bool(lo <= S_m <= hi),
                  "plain_ms_per_token": plain_ms, "speedup_vs_plain": None if not plain_ms else round(S_m * plain_ms / step_ms, 3),
                  "equals_plain_greedy_for": f"{n_same} of the first {n_chk} generated tokens",
+                 "greedy_check": greedy_check(live_prompt, gen_all, 64),
                  "how": "live weights, embedding scale searched (tied to lm_head, periodic prompt, POOL_FROM_PROMPT=1) for a step compression inside the range "
                         "BASELINE.md quotes for real checkpoints (1.6-2.3); speedup_vs_plain = S x plain one-token step / lookahead step on the same engine"}
         eng.lm_head = saved_head
