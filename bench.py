@@ -612,14 +612,34 @@ def worker(args):
             return ld, (len(ld.tokens) - t0_tok) / n_steps, time.perf_counter() - t0, infos_
 
         tried, best = [], None
-        for scale in (24.0, 32.0, 40.0, 48.0, 56.0, 64.0, 80.0, 96.0, 128.0, 192.0, 256.0):
-            _ld, S_t, _t, _i = trial(scale, 16)
-            tried.append([scale, round(S_t, 2)])
+
+        def probe(scale):
+            nonlocal best
+            _ld, S_t, _t, _i = trial(scale, args.steps)
+            tried.append([round(scale, 2), round(S_t, 2)])
             d = 0.0 if lo <= S_t <= hi else min(abs(S_t - lo), abs(S_t - hi))
             if best is None or d < best[0]:
                 best = (d, scale)
-            if d == 0.0 or S_t > hi:
+            return S_t
+
+        below, above = None, None                    # the ladder first; a random model switches from "never accepts" to "always accepts" within
+        for scale in (24.0, 32.0, 40.0, 48.0, 56.0, 64.0, 80.0, 96.0, 128.0, 192.0, 256.0):       # a factor of 1.2-1.5 in scale, so the bracket is bisected
+            S_t = probe(scale)
+            if S_t < lo:
+                below = scale
+            elif S_t > hi:
+                above = scale
+            if best[0] == 0.0 or above is not None:
                 break
+        for _ in range(6):
+            if best[0] == 0.0 or below is None or above is None:
+                break
+            mid = math.sqrt(below * above)
+            S_t = probe(mid)
+            if S_t < lo:
+                below = mid
+            elif S_t > hi:
+                above = mid
         scale = best[1]
         ld, S_m, tl, li = trial(scale, args.steps)
         gen_all = ld.tokens[len(live_prompt):]
