@@ -751,6 +751,14 @@ def worker(args):
                                           if eng.rows_kept < eng.rows_total else
                                           f"decode GEMMs stream a K-tile-major copy of the projection weights (+{eng.ktile_bytes / 1e9:.1f} GB of HBM); "
                                           "prefill uses the row-major ones") if eng.ktile else "row-major (LADE_W_KTILE=0)"),
+                       **({"lp_expectation": (f"strong scaling: the {(N - 1) * W}-row step of one rank is split over the ranks (rank 0 feeds {round(avg_T, 1)} rows); "
+                                              + ("at W=15 the one-rank step is already a weight stream (1.15 x the one-token step), so 1 -> 8 ranks is <= 1.15 x by "
+                                                 "construction; --config lp7b / lp70b (the reference's default W=60 N=8 G=60) is the regime lookahead parallelism is built for: "
+                                                 "every rank's shard timed on one GPU gives 10.05 -> 6.93 -> 6.10 -> 4.64 ms cold at 1 / 2 / 4 / 8 ranks, 2.17 x "
+                                                 "(profiles/r4_lp_curve_7b.txt, DESIGN section 6)" if W < 40 else
+                                                 "the reference's default configuration: every rank's shard timed on one GPU gives 10.05 -> 6.93 -> 6.10 -> 4.64 ms cold at "
+                                                 "1 / 2 / 4 / 8 ranks for the 7B shape (profiles/r4_lp_curve_7b.txt, DESIGN section 6), plus one int32 all-gather per step"))}
+                          if use_lp else {}),
                        **({"shared_gpu": True, "backend": backend} if share_gpu else {})},
             "step_compression": round(S, 3), "steps_per_s": round(args.steps / elapsed, 2), "spread": spread,
             "prefill": {"tokens": args.prompt_len + W + N - 3, "ms": round(prefill_s * 1e3, 2), "tokens_per_s": round((args.prompt_len + W + N - 3) / prefill_s, 1),
