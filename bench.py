@@ -356,7 +356,7 @@ def worker(args):
     # pool drift by several per cent between consecutive runs of one binary, a single 80 ms block says nothing about that
     block_ms = [elapsed / args.steps * 1e3]
     block_max = [None]                                            # [slowest step (ms, host clock), its index] of the blocks after the contract's
-    block_T = [round(sum(i.get("T", 0) for i in infos) / max(1, len(infos)), 1)]      # rows fed per step: a block whose steps carry candidates feeds more
+    block_T = [round(sum((i.get("T") or 0) for i in infos) / max(1, len(infos)), 1)]      # rows fed per step: a block whose steps carry candidates feeds more
     for _ in range(max(0, args.blocks - 1)):
         sync()
         tb0 = time.perf_counter()
@@ -365,7 +365,7 @@ def worker(args):
             binf.append(run.step())
             marks.append(time.perf_counter())
         sync()
-        block_T.append(round(sum(i.get("T", 0) for i in binf) / max(1, len(binf)), 1))
+        block_T.append(round(sum((i.get("T") or 0) for i in binf) / max(1, len(binf)), 1))
         gaps = [(b - a) * 1e3 for a, b in zip(marks, marks[1:])]
         block_max.append([round(max(gaps), 3), gaps.index(max(gaps))])
         tb = time.perf_counter() - tb0
@@ -374,6 +374,7 @@ def worker(args):
             dist.all_reduce(tb_t, op=dist.ReduceOp.MAX)
             tb = float(tb_t[0].item())
         block_ms.append(tb / args.steps * 1e3)
+    block_T = [t or None for t in block_T]                        # lookahead-parallel steps do not report a row count (each rank feeds its own shard)
     srt = sorted(block_ms)
     spread = {"blocks": len(block_ms), "steps_per_block": args.steps, "ms_per_step_median": round(srt[len(srt) // 2], 3), "ms_per_step_min": round(srt[0], 3),
               "ms_per_step_max": round(srt[-1], 3), "ms_per_step_blocks": [round(x, 3) for x in block_ms], "rows_per_step_blocks": block_T, "slowest_step_ms_and_index_blocks": block_max,

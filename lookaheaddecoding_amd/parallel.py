@@ -257,14 +257,16 @@ class HipLPBackend:
         state = (st.ctl, st.window, st.pool_cnt, st.pool_tok, st.guess, st.tail)
         with HipLPBackend._capture_lock:           # one capture at a time per process (ranks may be threads in the tests)
             saved = [t.clone() for t in state]
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                self._segment_body(n_input, ls, c0, c1, gcap, sel, n_splits)       # warm-up: library handles, autotune
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            for t, sv in zip(state, saved):
-                t.copy_(sv)
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    self._segment_body(n_input, ls, c0, c1, gcap, sel, n_splits)       # warm-up: library handles, autotune
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+            finally:                                   # whatever the warm-up did to the integer state is undone - also when it failed (LPRunner falls back to eager steps)
+                for t, sv in zip(state, saved):
+                    t.copy_(sv)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self._segment_body(n_input, ls, c0, c1, gcap, sel, n_splits)
@@ -412,7 +414,18 @@ class LPRunner:
         glo, ghi = guess_shard(self.g, R, r) if phase == 2 else (0, 0)
         # (dynamic-NTK RoPE: a padded graph segment would count its padding as sequence length - those models take the eager LP step)
         if phase == 2 and getattr(self.dec, "use_graph", False) and hasattr(self.be, "local_step_graph") and getattr(self.dec.e, "ntk_state", None) is None:
-            rec = self.be.local_step_graph(self.P, self.n_input, level_lens, c0, c1, ghi - glo)
+            try:
+                rec = self.be.local_step_graph(self.P, self.n_input, level_lens, c0, c1, ghi - glo)
+            except (RuntimeError, OSError) as ex:
+                if type(ex).__name__ == "LadeHipError":
+                    raise                                 # a refusal of the step itself (cache exhausted ...), not of the capture
+                # the hipGraph segment could not be captured / replayed on this box (never exercised next to a multi-GPU RCCL communicator
+                # before round 5): this rank takes the eager step from here on - the other ranks need not, the step's collective is the same
+                import sys
+                print(f"[lade] rank {r}: hipGraph segment unavailable ({type(ex).__name__}: {str(ex)[:200]}); eager lookahead-parallel steps from here on",
+                      file=sys.stderr, flush=True)
+                self.dec.use_graph = False
+                rec = self.be.local_step(phase, self.P, self.n_input, level_lens, c0, c1, self.g, glo, ghi)
         else:
             rec = self.be.local_step(phase, self.P, self.n_input, level_lens, c0, c1, self.g, glo, ghi)
         self.all_gather(self.all_rec, rec)                                       # the ONE exchange of the step

@@ -225,6 +225,29 @@ def test_lp_graph_segments_single_rank_equals_single_gpu_runs():
         assert res[0][0] == run["tokens"] and res[0][1] == run["steps"]
 
 
+def test_lp_rank_whose_graph_segment_fails_falls_back_to_eager_steps_and_keeps_the_stream(monkeypatch, capfd):
+    """A hipGraph segment that cannot be captured or replayed (the path has never run next to a multi-GPU RCCL communicator) must not end
+    the run: the rank restores the integer state the warm-up touched, takes eager lookahead-parallel steps from there on and the
+    tokens / steps stay those of the reference's run.  Forced here by a forward() that fails once, inside the segment's warm-up."""
+    from lookaheaddecoding_amd.engine import StepEngine
+    with open(os.path.join(GOLDEN, "e2e_greedy.json")) as f:
+        run = json.load(f)["runs"][1]
+    orig = StepEngine.forward
+    state = {"armed": True}
+
+    def flaky(self, *a, **k):
+        if state["armed"] and k.get("dyn_P") is not None:          # the first device-length forward = the first segment's warm-up
+            state["armed"] = False
+            raise RuntimeError("simulated capture failure")
+        return orig(self, *a, **k)
+
+    monkeypatch.setattr(StepEngine, "forward", flaky)
+    res = _lp_graph_threads(run, 1)
+    assert not state["armed"], "the failure was never injected"
+    assert res[0][0] == run["tokens"] and res[0][1] == run["steps"]
+    assert "eager lookahead-parallel steps from here on" in capfd.readouterr().err
+
+
 def test_lp_loop_on_the_c_abi_communicator_without_torch_distributed(tmp_path):
     """A caller without torch.distributed: RcclComm built over a byte channel (here a world of one rank, so none is needed), handed to the
     package's lookahead-parallel loop - the step's all-gather, the window broadcast and the GEMM-table adoption all go through

@@ -22,11 +22,15 @@ rm -rf /tmp/kt
 grep "^{" /tmp/kt.log > $OUT/bench_c2_under_rocprof.json
 cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $OUT/bench_c2_kernel_stats.csv
 python tools/trace_medians.py $(find /tmp/kt -name "*kernel_trace.csv" | head -1) --steps > $OUT/bench_c2_kernel_medians.txt
-# 3. counters of the attention pair at the bench's own launch shapes
+# 3. counters of the attention pair at the bench's own launch shapes (SKIP_PMC=1: the attention kernels did not change since the last pass)
+if [ "${SKIP_PMC:-0}" != "1" ]; then
 P_END=$(python -c "import json; print(json.load(open('$OUT/bench_c2.json'))['config']['kv_len_end'])")
 bash tools/attn_pmc.sh $OUT/attn_pmc.json $P_END > $OUT/attn_pmc.log 2>&1; tail -4 $OUT/attn_pmc.log
+fi
 # 4. the lookahead-parallel regime: the reference's default W=60 N=8 G=60 on one rank, and every rank's shard at R = 1 / 2 / 4 / 8
+if [ "${SKIP_LP:-0}" != "1" ]; then
 timeout 900 python bench.py --config lp7b --gpus 1 --steps 16 --warmup 4 --no-cpu-baseline --blocks 2 2> $OUT/bench_lp7b.err | grep "^{" > $OUT/bench_lp7b.json
 echo "bench lp7b rc=$? $(cut -c1-150 $OUT/bench_lp7b.json)"
 timeout 900 python tools/lp_curve.py 7b 60 8 60 2>&1 | grep -v amdgpu.ids > $OUT/lp_curve_7b.txt; tail -8 $OUT/lp_curve_7b.txt | cut -c1-200
+fi
 ls -la $OUT
