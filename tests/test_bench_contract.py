@@ -33,6 +33,14 @@ def test_committed_bench_line_has_the_contract_fields():
     m = d["mid_regime"]
     assert m["unit"] == "tokens/s" and abs(m["speedup_vs_plain"] - m["step_compression"] * m["plain_ms_per_token"] / m["ms_per_step"]) < 0.01
     assert m["in_published_range"] == (1.6 <= m["step_compression"] <= 2.3) and "of the first 64 generated tokens" in m["equals_plain_greedy_for"]
+    # every emitted token against the plain one-token step on its own prefix: the plain argmax, or within a few spacings of the dtype
+    for k in ("mid_regime", "hot_regime"):
+        gc_ = d[k]["greedy_check"]
+        assert gc_["tokens"] == 64 and gc_["plain_argmax_of_own_prefix"] >= 60 and gc_["in_dtype_spacings"] <= 4.0, (k, gc_)
+    # the blocks after the contract's: rows fed per step and the slowest step - no collector stall (a 37-44 ms step) any more
+    sp = d["spread"]
+    assert len(sp["rows_per_step_blocks"]) == sp["blocks"] and all(r >= 60.0 for r in sp["rows_per_step_blocks"])
+    assert sp["slowest_step_ms_and_index_blocks"][0] is None and all(m < 2.0 * d["ms_per_step"] for m, _i in sp["slowest_step_ms_and_index_blocks"][1:])
     g = d["step_gpu_only"]
     assert g["valid"] and abs(g["host_turnaround_us_per_step"] - (d["ms_per_step"] - g["ms_per_step_back_to_back"]) * 1e3) < 1.0 and abs(g["host_turnaround_us_per_step"]) < 30
 
