@@ -165,14 +165,25 @@ class LookaheadDecoder:
         self.finished_by_eos = False
 
     # ---- steady step as ONE hipGraph ------------------------------------------------------------------
-    # Fixed shapes: a graph is captured per candidate-count bucket gcap in {0, G/4, G/2, G}; a step with g
-    # candidates replays the smallest bucket >= g and feeds T = (N-1)(W+gcap) tokens - the gcap-g unused
-    # candidate slots are padded with token 0 (they only see themselves and the input token, and verify
-    # ignores them).  The cache length P is read by the kernels from the control block (dyn_P), so the same
-    # graphs serve every step: a step is one graph launch plus the read-back of the 24-word record.
+    # Fixed shapes: a graph is captured per candidate-count bucket gcap; a step with g candidates replays the
+    # smallest bucket >= g and feeds T = (N-1)(W+gcap) tokens - the gcap-g unused candidate slots are padded
+    # with token 0 (they only see themselves and the input token, and verify ignores them).  The cache length
+    # P is read by the kernels from the control block (dyn_P), so the same graphs serve every step: a step is
+    # one graph launch plus the read-back of the 24-word record.
+    # The buckets follow the GEMM row classes of the engine (32-row activation blocks: a step of 61..64 rows
+    # costs what one of 60 does, one of 65 pays for 96): bucket = the most candidates that still fit each
+    # class (+ G/4).  Config 2 (W=15 N=5 G=15): {0, 1, 4, 9, 15} = 60 / 64 / 76 / 96 / 120 rows - a step that carries ONE
+    # candidate (the common case while n-grams are being accepted) runs at the cold step's cost instead of a
+    # 76-row step's (+12 %).  Beyond the last class (T > 256: library GEMMs) the old quartiles {0, G/4, G/2, G}.
     def _buckets(self) -> List[int]:
-        G = self.G
-        return sorted({0, (G + 3) // 4, (G + 1) // 2, G})
+        G, W, n1 = self.G, self.W, self.N - 1
+        classes = [c for c in getattr(self.e, "ROW_CLASSES", ()) if c >= n1 * W]
+        if not classes or G == 0:
+            return sorted({0, (G + 3) // 4, (G + 1) // 2, G})
+        fit = {min(G, c // n1 - W) for c in classes}
+        # + G/4: inside one GEMM class fewer padded rows still save attention / lm_head / glue rows (live hot regime of config 2:
+        # g = 2..4 at 76 rows 4.33 ms, at 96 rows 4.45)
+        return sorted({0, (G + 3) // 4, G} | {b for b in fit if b > 0})
 
     def _bucket_for(self, g: int) -> int:
         fits = [b for b in self._graphs if b >= g]

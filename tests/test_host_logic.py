@@ -172,3 +172,24 @@ def test_gemm_tune_table_round_trips_through_its_int32_block():
     words = encode_tune_table(table, names, classes)
     assert len(words) == 7 * len(names) * len(classes) and all(isinstance(w, int) for w in words)
     assert decode_tune_table(words, names, classes) == table
+
+
+def test_graph_buckets_follow_the_gemm_row_classes():
+    """LookaheadDecoder._buckets: the candidate counts a steady-step hipGraph is captured for = the most candidates that still fit each
+    32-row GEMM class of the engine, + G/4, + {0, G}: a step with one candidate pads to 64 rows (config 2) / 126 rows (config 4), not to
+    76 / 150; beyond the last class (the reference's default W=60 N=8 G=60: 420+ rows) the quartiles."""
+    from types import SimpleNamespace
+    from lookaheaddecoding_amd.decoding import LookaheadDecoder
+    classes = (32, 64, 96, 128, 192, 256)
+
+    def buckets(W, N, G):
+        return LookaheadDecoder._buckets(SimpleNamespace(W=W, N=N, G=G, e=SimpleNamespace(ROW_CLASSES=classes)))
+
+    assert buckets(15, 5, 15) == [0, 1, 4, 9, 15]
+    assert [(5 - 1) * (15 + b) for b in buckets(15, 5, 15)] == [60, 64, 76, 96, 120]
+    assert buckets(20, 7, 20) == [0, 1, 5, 12, 20]
+    assert buckets(60, 8, 60) == [0, 15, 30, 60]
+    assert buckets(15, 5, 0) == [0]
+    for W, N, G in ((5, 3, 5), (7, 4, 7), (10, 5, 10), (5, 4, 5), (15, 5, 15), (20, 7, 20)):
+        b = buckets(W, N, G)
+        assert b[0] == 0 and b[-1] == G and b == sorted(set(b))
