@@ -547,7 +547,11 @@ def worker(args):
             one_pos.fill_(Pq)
             logits = eng.forward(one_id, one_pos, ops.StepMask(T=1, P=Pq, is_prefill=True), sel0, 1)
             Pq += 1
-        return {"tokens": n_chk, "plain_argmax_of_own_prefix": same, "worst_margin_where_not": round(worst, 4), "in_dtype_spacings": round(worst_ulp, 2)}
+        return {"tokens": n_chk, "plain_argmax_of_own_prefix": same, "worst_margin_where_not": round(worst, 4), "in_dtype_spacings": round(worst_ulp, 2),
+                "note": "teacher forced: each emitted token vs the plain one-token step on the stream's own prefix.  The live-weights models are made copy-biased by "
+                        "scaling the embedding, which saturates their attention (scores grow with the square of the scale): a rounding-level tie between two keys "
+                        "can move a logit by several spacings, more so the wider the model - informative here, the parity bar on unscaled weights is "
+                        "tests/test_gpu_parity_shapes.py (the reference's own 16-bit envelope)"}
 
     def hot_live():
         # the embedding scale that makes a random model copy-biased grows with its depth and width: powers of two (exact in bf16, exactly
