@@ -171,6 +171,108 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_rows_kernel(const void* log
         if (i0 + e < V) o[i0 + e] = key_float(key[e]);
 }
 
+// ---- vocabularies beyond one work-group's registers (V > 32768: Llama-3-class) ------------------------------------------------------
+// The same algorithm, tie rules and fixed-point masses.  The row's keys live in the OUTPUT row (its fp32 slots hold the 32-bit keys until
+// the last pass) instead of registers; token i belongs to thread i % 1024 (coalesced accesses, the row stays in L2 between the passes);
+// a mass is recomputed from its key where the register kernel keeps it; top-k's removals are applied on the fly (a key below the top-k
+// cut reads as -inf).  A thread only ever touches its own tokens, so the passes need no barriers besides those of the reductions.  The
+// final pass walks the tokens in order and removes the first c members of the boundary's tie group: a work-group scan per 1024 tokens,
+// taken only until c are found.
+template <typename T>
+__global__ __launch_bounds__(WARP_THREADS) void warp_rows_big_kernel(const void* logits, int64_t ld, int V, float temperature, int top_k, float top_p,
+                                                                     int skip, float* out) {
+    __shared__ unsigned long long red64[2 * WARP_WAVES];
+    __shared__ uint32_t red32[2 * WARP_WAVES];
+    int t64 = 0, t32 = 0;
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int prow = row == 0 ? 0 : row + skip;
+    const uint32_t KEY_NEG_INF = 0x007fffffu;
+    uint32_t* kb = reinterpret_cast<uint32_t*>(out + (size_t)row * V);
+
+    uint32_t kmax = 0;
+    for (int i = tid; i < V; i += WARP_THREADS) {
+        float v = load_logit<T>(logits, (size_t)prow * ld + i);
+        if (temperature != 1.0f) v = v / temperature;
+        const uint32_t k = float_key(v);
+        kb[i] = k;
+        kmax = k > kmax ? k : kmax;
+    }
+
+    uint32_t Ktop = 0;                                  // top-k: keys below it read as -inf from here on
+    if (top_k > 0 && top_k < V) {
+        for (int b = 31; b >= 0; --b) {
+            const uint32_t t = Ktop | (1u << b);
+            uint32_t c = 0;
+            for (int i = tid; i < V; i += WARP_THREADS) c += kb[i] >= t ? 1u : 0u;
+            if (wg_sum<uint32_t>(c, red32, t32) >= (uint32_t)top_k) Ktop = t;
+        }
+    }
+    auto eff = [&](uint32_t k) { return k < Ktop ? KEY_NEG_INF : k; };
+
+    uint32_t K = 0;                                     // top-p: keys below it are removed, its own tie group partly
+    unsigned long long c_rm = 0;
+    if (top_p < 1.0f) {
+        kmax = wg_max<uint32_t>(kmax, red32, t32);      // (top-k never removes the largest key)
+        const float mx = key_float(kmax);
+        auto mass = [&](uint32_t k) {                   // of a key that is not removed
+            return (unsigned long long)((double)__expf(key_float(k) - mx) * 1099511627776.0 + 0.5);
+        };
+        unsigned long long z = 0;
+        for (int i = tid; i < V; i += WARP_THREADS) {
+            const uint32_t k = eff(kb[i]);
+            if (k > KEY_NEG_INF) z += mass(k);
+        }
+        const unsigned long long Z = wg_sum<unsigned long long>(z, red64, t64);
+        const float theta = (float)(1.0 - (double)top_p);
+        unsigned long long Theta = (unsigned long long)((double)theta * (double)Z);
+        if (Theta >= Z) Theta = Z - 1;
+        for (int b = 31; b >= 0; --b) {
+            const uint32_t t = K | (1u << b);
+            unsigned long long mlt = 0;
+            for (int i = tid; i < V; i += WARP_THREADS) {
+                const uint32_t k = eff(kb[i]);
+                if (k > KEY_NEG_INF && k < t) mlt += mass(k);
+            }
+            if (wg_sum<unsigned long long>(mlt, red64, t64) <= Theta) K = t;
+        }
+        unsigned long long below = 0, e_tie = 0;
+        for (int i = tid; i < V; i += WARP_THREADS) {
+            const uint32_t k = eff(kb[i]);
+            if (k > KEY_NEG_INF && k < K) below += mass(k);
+            if (k == K && k > KEY_NEG_INF) e_tie = mass(k);
+        }
+        const unsigned long long B = wg_sum<unsigned long long>(below, red64, t64);
+        const unsigned long long Et = wg_max<unsigned long long>(e_tie, red64, t64);
+        c_rm = (Et > 0 && Theta >= B) ? (Theta - B) / Et : 0ull;
+    }
+
+    // ---- last pass, in token order: keys -> values; below K removed; the first c_rm members of K's tie group removed ----
+    unsigned long long base = 0;                        // tie members in the tokens walked so far (uniform)
+    for (int j0 = 0; j0 < V; j0 += WARP_THREADS) {
+        const int i = j0 + tid;
+        const bool valid = i < V;
+        uint32_t k = valid ? eff(kb[i]) : 0u;
+        const bool tie = valid && top_p < 1.0f && k == K;
+        if (base < c_rm) {                              // uniform: the scan is only needed until c_rm members have been found
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(tie);
+            const uint32_t before = (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+            uint32_t* sc = red32 + (t32 & 1) * WARP_WAVES;
+            t32 ^= 1;
+            if (lane == 0) sc[wave] = (uint32_t)__builtin_popcountll(m);
+            __syncthreads();
+            uint32_t pre = before, total = 0;
+#pragma unroll
+            for (int w = 0; w < WARP_WAVES; ++w) { pre += w < wave ? sc[w] : 0u; total += sc[w]; }
+            if (tie && base + pre < c_rm) k = KEY_NEG_INF;
+            base += total;
+        }
+        if (valid) {
+            if (top_p < 1.0f && k < K) k = KEY_NEG_INF;
+            reinterpret_cast<float*>(kb)[i] = key_float(k);
+        }
+    }
+}
+
 }  // namespace lade
 
 using namespace lade;
@@ -179,9 +281,16 @@ extern "C" int lade_warp_rows(const void* logits, int64_t ld, int32_t rows, int3
                               float top_p, int32_t skip, float* out, void* stream) {
     LADE_REQUIRE(logits && out && rows >= 0 && V > 0 && ld >= V && temperature > 0.f && top_k >= 0 && top_p > 0.f && skip >= 0, LADE_E_ARG,
                  "lade_warp_rows: rows=%d V=%d T=%f top_k=%d top_p=%f skip=%d", rows, V, temperature, top_k, top_p, skip);
-    LADE_REQUIRE(V <= WARP_THREADS * WARP_EPT, LADE_E_LIMIT, "lade_warp_rows: V=%d > %d (a row is held in one work-group's registers)", V, WARP_THREADS * WARP_EPT);
+    LADE_REQUIRE(V <= (1 << 24), LADE_E_LIMIT, "lade_warp_rows: V=%d > %d", V, 1 << 24);
     if (rows == 0) return LADE_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (V > WARP_THREADS * WARP_EPT) {                  // the row does not fit one work-group's registers: keys in the output row
+        if (dtype == LADE_F32) hipLaunchKernelGGL(warp_rows_big_kernel<F32>, dim3(rows), dim3(WARP_THREADS), 0, st, logits, ld, V, temperature, top_k, top_p, skip, out);
+        else if (dtype == LADE_BF16) hipLaunchKernelGGL(warp_rows_big_kernel<BF16>, dim3(rows), dim3(WARP_THREADS), 0, st, logits, ld, V, temperature, top_k, top_p, skip, out);
+        else if (dtype == LADE_F16) hipLaunchKernelGGL(warp_rows_big_kernel<F16>, dim3(rows), dim3(WARP_THREADS), 0, st, logits, ld, V, temperature, top_k, top_p, skip, out);
+        else LADE_REQUIRE(false, LADE_E_DTYPE, "lade_warp_rows: dtype=%d", dtype);
+        return check_launch("lade_warp_rows");
+    }
     if (dtype == LADE_F32) hipLaunchKernelGGL(warp_rows_kernel<F32>, dim3(rows), dim3(WARP_THREADS), 0, st, logits, ld, V, temperature, top_k, top_p, skip, out);
     else if (dtype == LADE_BF16) hipLaunchKernelGGL(warp_rows_kernel<BF16>, dim3(rows), dim3(WARP_THREADS), 0, st, logits, ld, V, temperature, top_k, top_p, skip, out);
     else if (dtype == LADE_F16) hipLaunchKernelGGL(warp_rows_kernel<F16>, dim3(rows), dim3(WARP_THREADS), 0, st, logits, ld, V, temperature, top_k, top_p, skip, out);

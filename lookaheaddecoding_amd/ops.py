@@ -242,7 +242,7 @@ def softmax_rows(logits: torch.Tensor, temperature: float = 1.0, out: Optional[t
     return probs
 
 
-WARP_MAX_V = 32768        # lade_warp_rows holds a row in one work-group's registers
+WARP_MAX_V = 1 << 24      # lade_warp_rows: a row of <= 32768 tokens lives in one work-group's registers, a larger one in the output row (L2)
 
 
 def warp_rows(logits: torch.Tensor, rows: int, skip: int, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0,

@@ -568,7 +568,7 @@ def test_warp_rows_equals_the_hf_warpers():
     import lade_oracle as O
     from lookaheaddecoding_amd import ops
     g = torch.Generator().manual_seed(0)
-    for V in (32000, 32016, 257, 5):
+    for V in (32000, 32016, 257, 5, 128256, 50257, 32769):      # beyond 32768 the row's keys live in the output row (warp_rows_big_kernel)
         n_phys, skip = 9, 3
         logits = (torch.randn(n_phys, V, generator=g) * 3.0)
         rows = n_phys - skip
@@ -599,27 +599,27 @@ def test_warp_rows_ties_follow_the_stable_order_and_dtypes():
     sort yields - within a tie group the lowest token ids go first - for bf16 / f16 / fp32 inputs; plus degenerate rows."""
     from lookaheaddecoding_amd import ops
     g = torch.Generator().manual_seed(1)
-    V = 32000
-    base = (torch.randn(6, V, generator=g) * 2.5)
-    for dt in (torch.bfloat16, torch.float16, torch.float32):
-        lg = base.to(torch.bfloat16).to(dt)                                  # bf16-granular values in every dtype
-        for (temp, k, p) in ((1.0, 0, 0.9), (0.8, 64, 0.9), (1.0, 200, 1.0), (0.5, 0, 0.6)):
-            ref = _warp_reference(lg, temp, k, p)
-            out = ops.warp_rows(lg.cuda(), 6, 0, temp, k, p).cpu()
-            for r in range(6):
-                # same number of survivors up to the one boundary token (fp32 vs exact cumulative sum, see above), and the SAME choice
-                # inside every tie group: the lowest token ids are removed first
-                n_out, n_ref = int((~torch.isinf(out[r])).sum()), int((~torch.isinf(ref[r])).sum())
-                assert abs(n_out - n_ref) <= 1, (dt, temp, k, p, r, n_out, n_ref)
-                diff = (torch.isinf(out[r]) != torch.isinf(ref[r])).nonzero().flatten().tolist()
-                assert len(diff) <= 1, (dt, temp, k, p, r, diff)
-                kept = (~torch.isinf(out[r])).nonzero().flatten()
-                vals = ref[r].clone(); vals[torch.isinf(vals)] = (lg[r].float() / temp if temp != 1.0 else lg[r].float())[torch.isinf(vals)]
-                cut = vals[kept].min()
-                tied = (vals == cut).nonzero().flatten()                      # the boundary value's tie group, in token order
-                tied_kept = ~torch.isinf(out[r][tied])
-                first_kept = int(tied_kept.nonzero()[0]) if tied_kept.any() else len(tied)
-                assert bool(tied_kept[first_kept:].all()) and not bool(tied_kept[:first_kept].any()), (dt, temp, k, p, r)
+    for V in (32000, 128256):                                               # registers / output-row form of the kernel
+        base = (torch.randn(6, V, generator=g) * 2.5)
+        for dt in (torch.bfloat16, torch.float16, torch.float32):
+            lg = base.to(torch.bfloat16).to(dt)                                  # bf16-granular values in every dtype
+            for (temp, k, p) in ((1.0, 0, 0.9), (0.8, 64, 0.9), (1.0, 200, 1.0), (0.5, 0, 0.6)):
+                ref = _warp_reference(lg, temp, k, p)
+                out = ops.warp_rows(lg.cuda(), 6, 0, temp, k, p).cpu()
+                for r in range(6):
+                    # same number of survivors up to the one boundary token (fp32 vs exact cumulative sum, see above), and the SAME choice
+                    # inside every tie group: the lowest token ids are removed first
+                    n_out, n_ref = int((~torch.isinf(out[r])).sum()), int((~torch.isinf(ref[r])).sum())
+                    assert abs(n_out - n_ref) <= 1, (dt, temp, k, p, r, n_out, n_ref)
+                    diff = (torch.isinf(out[r]) != torch.isinf(ref[r])).nonzero().flatten().tolist()
+                    assert len(diff) <= 1, (dt, temp, k, p, r, diff)
+                    kept = (~torch.isinf(out[r])).nonzero().flatten()
+                    vals = ref[r].clone(); vals[torch.isinf(vals)] = (lg[r].float() / temp if temp != 1.0 else lg[r].float())[torch.isinf(vals)]
+                    cut = vals[kept].min()
+                    tied = (vals == cut).nonzero().flatten()                      # the boundary value's tie group, in token order
+                    tied_kept = ~torch.isinf(out[r][tied])
+                    first_kept = int(tied_kept.nonzero()[0]) if tied_kept.any() else len(tied)
+                    assert bool(tied_kept[first_kept:].all()) and not bool(tied_kept[:first_kept].any()), (dt, temp, k, p, r)
     # all logits equal: top-p removes the lowest token ids until the mass left exceeds top_p; top-k keeps every tie
     flat = torch.zeros(2, 1000)
     out = ops.warp_rows(flat.cuda(), 2, 0, 1.0, 10, 1.0).cpu()
@@ -628,6 +628,12 @@ def test_warp_rows_ties_follow_the_stable_order_and_dtypes():
     ref = _warp_reference(flat, 1.0, 0, 0.25)
     assert abs(int(torch.isinf(out[0]).sum()) - int(torch.isinf(ref[0]).sum())) <= 1 and not torch.isinf(out[0, -1])
     assert torch.isinf(out[0, :700]).all()                                   # the removed ones are the lowest ids
+    flat_big = torch.zeros(1, 40000)                                         # the same through the output-row form: the tie group spans 40 scans
+    out = ops.warp_rows(flat_big.cuda(), 1, 0, 1.0, 0, 0.25).cpu()
+    ref = _warp_reference(flat_big, 1.0, 0, 0.25)
+    assert abs(int(torch.isinf(out[0]).sum()) - int(torch.isinf(ref[0]).sum())) <= 1 and not torch.isinf(out[0, -1])
+    n_rm = int(torch.isinf(out[0]).sum())
+    assert 29990 <= n_rm <= 30010 and torch.isinf(out[0, :n_rm]).all() and not torch.isinf(out[0, n_rm:]).any()
     # a row that already holds -inf entries (a second warp, or a masked vocabulary)
     holes = base[:1].clone()
     holes[0, ::3] = -float("inf")
