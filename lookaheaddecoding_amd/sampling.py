@@ -28,8 +28,8 @@ class Warper:
     """Temperature -> top-k -> top-p on [rows, V] fp32 logits (same order and tie rules as HF's TemperatureLogitsWarper /
     TopKLogitsWarper / TopPLogitsWarper).  With top-k and top-p off the warp is a plain scale, which the device kernels apply
     themselves (`fused_temperature`); otherwise the sampling loop calls `warp_rows` - one HIP launch (lade_warp_rows: no sort, no
-    topk) - and `__call__` (torch ops on whatever device the logits are on) remains for vocabularies beyond that kernel and as the
-    plain statement of the semantics."""
+    topk; beyond 32768 tokens its output-row form) - and `__call__` (torch ops on whatever device the logits are on) remains for CPU
+    tensors and as the plain statement of the semantics."""
 
     def __init__(self, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0):
         self.temperature, self.top_k, self.top_p = float(temperature), int(top_k or 0), float(top_p)
@@ -40,7 +40,7 @@ class Warper:
 
     def warp_rows(self, logits: torch.Tensor, rows: int, skip: int) -> Optional[torch.Tensor]:
         """The warp of logical rows 0 and 1 + skip .. (the out row and the candidate rows of a step's logits) as ONE device launch
-        (lade_warp_rows); None when the vocabulary exceeds what that kernel holds - the caller then uses __call__ (torch ops)."""
+        (lade_warp_rows); None for a CPU tensor or a vocabulary beyond 2^24 - the caller then uses __call__ (torch ops)."""
         from . import ops
         if not logits.is_cuda or logits.shape[-1] > ops.WARP_MAX_V:
             return None
