@@ -835,9 +835,26 @@ def main():
     # `python bench.py --gpus N`: start the N ranks ourselves, one process per GPU, RCCL over xGMI between them
     if torch.cuda.device_count() < args.gpus and os.environ.get("LADE_BENCH_SHARE_GPU") != "1":
         raise SystemExit(f"--gpus {args.gpus}: this box has {torch.cuda.device_count()} GPU(s)")
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    # a rendezvous port BELOW the kernel's ephemeral range: one obtained from bind(0) can be handed to any outgoing connection of the box
+    # before rank 0's TCPStore binds it (the ranks build their weights first) - rank 0 then dies with EADDRINUSE and the others wait
+    # (diagnosed in round 4: profiles/r4_lp_stall.txt)
+    try:
+        with open("/proc/sys/net/ipv4/ip_local_port_range") as f:
+            lo = int(f.read().split()[0])
+    except (OSError, ValueError, IndexError):
+        lo = 32768
+    port, rnd = None, random.Random(os.getpid() ^ time.time_ns())
+    for _ in range(128):
+        cand = rnd.randrange(max(10000, max(lo, 14000) - 16000), max(lo, 14000))
+        with socket.socket() as s:
+            try:
+                s.bind(("127.0.0.1", cand))
+            except OSError:
+                continue
+        port = cand
+        break
+    if port is None:
+        raise SystemExit("no free rendezvous port below the ephemeral range")
     import torch.multiprocessing as mp
     mp.spawn(_spawned, args=(args.gpus, port, sys.argv[1:]), nprocs=args.gpus, join=True)
 

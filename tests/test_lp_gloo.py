@@ -13,12 +13,7 @@ import torch.multiprocessing as mp
 from conftest import GOLDEN, ROOT
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+from conftest import free_port as _free_port      # outside the ephemeral range: see its docstring
 
 
 def _worker(rank, R, port, run, q):
