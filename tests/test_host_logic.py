@@ -193,3 +193,21 @@ def test_graph_buckets_follow_the_gemm_row_classes():
     for W, N, G in ((5, 3, 5), (7, 4, 7), (10, 5, 10), (5, 4, 5), (15, 5, 15), (20, 7, 20)):
         b = buckets(W, N, G)
         assert b[0] == 0 and b[-1] == G and b == sorted(set(b))
+
+
+def test_rendezvous_ports_are_picked_below_the_ephemeral_range():
+    """conftest.free_port: a port the kernel cannot hand to an outgoing connection between the probe and the TCPStore's bind (the diagnosed
+    cause of the 1-in-50 start-up stall: EADDRINUSE at rank 0, the other ranks waiting for a store that never comes)."""
+    import socket
+    from conftest import free_port
+    try:
+        with open("/proc/sys/net/ipv4/ip_local_port_range") as f:
+            lo = int(f.read().split()[0])
+    except OSError:
+        lo = 32768
+    for _ in range(8):
+        p = free_port()
+        assert 10000 <= p < max(lo, 14000)
+        s = socket.socket()
+        s.bind(("127.0.0.1", p))          # really free
+        s.close()
