@@ -2,7 +2,12 @@
 after another process had torn down an RCCL communicator on the same GPU; VERDICT r3 "weak" item 1).  Repeats, N times: (a) the 1-rank
 RCCL process of `test_config_lade_dist_workers_generate_one_rccl_rank`, then immediately (b) the 2-rank gloo run sharing the GPU - with
 NCCL_DEBUG=INFO and a 45 s faulthandler watchdog in every worker - and records per run: wall seconds of each process, where a stalled
-rank was (the faulthandler dump), and the last RCCL / gloo lines before it.   python tools/lp_stall_repro.py [N] > gpurun_out/lp_stall.txt"""
+rank was (the faulthandler dump), and the last RCCL / gloo lines before it.   python tools/lp_stall_repro.py [N] > gpurun_out/lp_stall.txt
+
+Result (round 4, profiles/r4_lp_stall.txt): 0 of 14, then 1 of 36 - and the one caught names the cause: rank 0's TCPStore failed to bind the
+rendezvous port (EADDRINUSE), rank 1 waited for the store.  The port had come from bind(0), i.e. from the kernel's ephemeral range, and was
+taken by another connection before rank 0 bound it.  Nothing of RCCL or the GPU; `tests/conftest.free_port` now picks below that range
+(this tool uses the test module's picker, so it now runs with the fix)."""
 import os
 import subprocess
 import sys
