@@ -20,6 +20,7 @@
  *   lade_rope_kv_append      apply_rotary_pos_emb + torch.cat KV append
  *                            lade/models/modeling_llama.py:321-346, :510-516
  *   lade_kv_commit           lade/decoding.py:1154-1163 (greedy) / :582-590 (sample)
+ *   lade_kv_pack_bshd        (adapter only) K / V as `flash_attn_func` receives them -> this library's cache layout
  *   lade_build_inputs        lade/models/modeling_llama.py:1463-1511 (ids / position_ids assembly)
  *   lade_argmax_rows / lade_argmax_pairs   torch.argmax(outputs.*_logits, dim=-1)  lade/decoding.py:1021,1041,1052,1072,1102
  *                            (pairs: on what the lm_head GEMM's argmax epilogue leaves instead of the logits)
@@ -57,7 +58,7 @@
 extern "C" {
 #endif
 
-#define LADE_ABI_VERSION 1
+#define LADE_ABI_VERSION 2      /* 2: lade_attn_args grew (wg_rows, fused RoPE), lade_gemm_skinny* take `ring`, lade_greedy_post_step takes record_host */
 
 /* error codes */
 #define LADE_OK 0
@@ -138,6 +139,21 @@ typedef struct lade_attn_args {
     int32_t n_splits;       /* >= 1 ; work-groups = ceil(n_rep*T/128) x H/n_rep x n_splits (1-D grid, XCD-aware order) */
     float scale;            /* softmax scale, 1/sqrt(d) */
     lade_mask_params mask;
+    /* ---- since LADE_ABI_VERSION 2 ---- */
+    int32_t wg_rows;        /* work-group shape: query rows of the (head-in-group, token) row space per work-group - 128 (4 x 2 waves, one 64-key
+                             * tile per stage), 64 or 32 (two tiles per stage, every wave computes); 0 = 128.  A launch parameter like the GEMM's
+                             * tile shape: the caller's in-step autotune picks it per launch shape together with n_splits */
+    /* Fused RoPE + KV append (n_parts > 0; bf16 / f16): q and the step's new K / V rows are taken from the qkv projection's fp32 split-K
+     * partials instead of from `q` and the cache - the work of lade_rope_kv_append_parts (lade/models/modeling_llama.py:321-346, :510-516)
+     * inside this launch, operation for operation: the rows P .. P+T of k_cache / vt_cache are WRITTEN (by the work-groups whose key range
+     * holds them) and the results are bit-identical to the two-launch form.  `q` may be null. */
+    int32_t n_parts;        /* 0 = off; 1..4 partials */
+    const float* qkv_parts; /* [n_parts][T][(H + 2 Hkv) d], part_stride elements apart */
+    int64_t part_stride;
+    const int32_t* positions;   /* [T] position ids (rows of the tables), or null: token t uses table row t (per-step gathered rows) */
+    const void* cos_tab;    /* [max_pos][d], model dtype */
+    const void* sin_tab;
+    int32_t max_pos;
 } lade_attn_args;
 
 int lade_attn_fwd(const lade_attn_args* a, void* stream);
@@ -177,6 +193,16 @@ int lade_rope_kv_append(void* qkv, const int32_t* positions, const void* cos_tab
 int lade_kv_commit(void* cache, int64_t layer_stride, int64_t v_offset, int32_t L, int32_t Hkv, int32_t d,
                    int32_t S_max, int32_t src, int32_t dst, int32_t cnt, const int32_t* ctl, int32_t max_cnt,
                    int32_t elem_bytes, void* stream);
+
+/* K / V in the layout the reference hands its flash kernel - [S][Hkv][d], token-major: `flash_attn_func(q, k, v, ...)` at
+ * lade/models/modeling_llama.py:705-713 after the transposes of :636-638 - re-laid into this library's cache layout: k_cache
+ * [Hkv][S_max][d], vt_cache [Hkv][d][S_max] (rows >= S untouched).  k and v share their strides (elements): tok_stride between tokens,
+ * head_stride between heads - Hkv*d and d for a contiguous [S][Hkv][d] tensor, d and S*d for the transposed VIEW of [Hkv][S][d] the
+ * reference really passes (:636-638 transpose without a copy).  One launch, every byte read and written once: the adapter
+ * `lookaheaddecoding_amd/flash_attn_lade.py:flash_attn_func` calls it per attention call, which costs about what the reference's own
+ * per-layer torch.cat of the whole cache costs (:626-629); the step engine never does - its cache is resident in this layout. */
+int lade_kv_pack_bshd(const void* k, const void* v, int64_t tok_stride, int64_t head_stride, void* k_cache, void* vt_cache, int32_t S,
+                      int32_t Hkv, int32_t d, int32_t S_max, int32_t elem_bytes, void* stream);
 
 /* ---- integer path (all bit-exact against the reference's python logic) ---------------- */
 
@@ -238,8 +264,11 @@ int lade_window_roll(int32_t* window, int32_t wcap, int32_t* ctl, const int32_t*
  * (P, lst_token, lst_pos, kv-commit triple, hits, step).
  * record = {max_hit, n_accept, finished_by_eos, g_next, P_next, max_hit_idx, first_guess, step number (ctl[STEP] after this step),
  * hits[gs], 0 ..., seal} - LADE_REC_WORDS words, the last one lade_record_seal() of the others.  record_host (nullable): the same
- * words are ALSO stored to this address - pinned host memory mapped into the device - followed by a system-scope fence, so that the
- * host can poll for the step's record instead of synchronising the stream (no copy node, no blocking wait in a steady step).
+ * words are ALSO stored to this address - pinned host memory mapped into the device - so that the host can poll for the step's record
+ * instead of synchronising the stream (no copy node, no blocking wait in a steady step).  NO fence follows those stores (fine-grained host
+ * memory takes them as they are issued, in any order): the seal, computed over all the other words, is the only ordering guarantee - a
+ * reader accepts a record only when the step number AND the seal match what it read, and must bound its wait (memory the device's stores do
+ * not reach coherently never shows the record).
  * eos < 0 disables the EOS scan; the scan follows lade/decoding.py:1167-1177.
  * Sampling (lade/decoding.py:137-692): the rejection-sampling verify runs on the host (it consumes the python
  * and torch RNG streams in the reference's order); its result is passed as forced = {max_hit, max_hit_idx,

@@ -16,6 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LADE_HIP_LIB") or os.path.join(_HERE, "liblade_hip.so")     # env override: kernel experiments
 
+ABI_VERSION = 2           # LADE_ABI_VERSION of include/lade_hip.h this binding was written against (checked at load time)
 LADE_BF16, LADE_F16, LADE_F32 = 0, 1, 2
 DTYPE_CODE = {torch.bfloat16: LADE_BF16, torch.float16: LADE_F16, torch.float32: LADE_F32}
 
@@ -48,7 +49,10 @@ class AttnArgs(C.Structure):
                 ("part_o", C.c_void_p), ("part_ml", C.c_void_p), ("dyn_P", C.c_void_p),
                 ("q_row_stride", C.c_int64), ("out_row_stride", C.c_int64),
                 ("H", C.c_int32), ("Hkv", C.c_int32), ("d", C.c_int32), ("S_max", C.c_int32),
-                ("dtype", C.c_int32), ("n_splits", C.c_int32), ("scale", C.c_float), ("mask", MaskParams)]
+                ("dtype", C.c_int32), ("n_splits", C.c_int32), ("scale", C.c_float), ("mask", MaskParams),
+                # ABI 2: work-group shape + fused RoPE / KV append (all zero = the ABI-1 behaviour)
+                ("wg_rows", C.c_int32), ("n_parts", C.c_int32), ("qkv_parts", C.c_void_p), ("part_stride", C.c_int64),
+                ("positions", C.c_void_p), ("cos_tab", C.c_void_p), ("sin_tab", C.c_void_p), ("max_pos", C.c_int32)]
 
 
 _lib: Optional[C.CDLL] = None
@@ -63,6 +67,7 @@ SIGNATURES = {
     "lade_rope_kv_append": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "lade_rope_rows_dynamic": [_vp, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _vp],
     "lade_kv_commit": [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp],
+    "lade_kv_pack_bshd": [_vp, _vp, _i64, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "lade_build_inputs": [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp],
     "lade_argmax_rows": [_vp, _i64, _i32, _i32, _i32, _vp, _vp],
     "lade_argmax_pairs": [_vp, _i32, _i32, _vp, _vp],
@@ -127,6 +132,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
             raise LadeHipError(f"{path} does not export {name}") from e
         fn.argtypes = argtypes
         fn.restype = C.c_char_p if name == "lade_last_error_string" else (C.c_uint32 if name == "lade_record_seal" else C.c_int)
+    got = lib.lade_version()
+    if got != ABI_VERSION:        # argument lists changed between versions: a stale build would read `epilogue` as `ring`, and so on
+        raise LadeHipError(f"{path} implements ABI version {got}, this binding expects {ABI_VERSION}: rebuild it (make -C lookaheaddecoding_amd/csrc)")
     _lib = lib
     return lib
 

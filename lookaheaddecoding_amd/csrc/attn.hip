@@ -53,6 +53,15 @@ struct AttnK {
     float inv_T;        // 1 / T, rounded once on the host
     int n_groups;       // row blocks x KV heads
     lade_mask_params m;
+    // fused RoPE + KV append (kernels with NPC > 0): q and the step's new K / V rows come from the qkv projection's fp32 split-K partials
+    const float* parts;          // [n_parts][T][row_w], part_stride elements apart
+    size_t part_stride;
+    const int32_t* positions;    // [T] or null (= table row t)
+    const uint16_t* cos_tab;     // [max_pos][D]
+    const uint16_t* sin_tab;
+    uint16_t* k_w;               // the caches again, writable
+    uint16_t* vt_w;
+    int n_parts, max_pos, row_w;
 };
 
 // ---- 1-D grid, XCD aware ---------------------------------------------------------------------------------------------------------
@@ -273,6 +282,68 @@ __device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "mem
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// ---- fused RoPE + KV append ------------------------------------------------------------------------------------------------------
+// The qkv projection of a decode step is a split-K GEMM that leaves fp32 partials; round 1-4 summed them, rotated q / k and appended the
+// new K / V rows in a launch of their own (lade_rope_kv_append_parts, 6.4-8.3 us per layer inside a step: latency, not bytes).  With
+// NPC > 0 the attention work-groups do it themselves - the seam is per head, not all-to-all: a work-group of KV head h needs the q rows
+// of its own heads (every split rebuilds them: 30 KB of fp32 per partial at T = 60) and, if its key range reaches into the new rows
+// P .. P+T, exactly those rows of K and V^T - which it writes to the cache (for the steps to come) and then streams back like any other
+// tile.  No work-group ever waits for another one: row blocks that share a KV head write the same bytes.  The arithmetic is
+// lade_rope_kv_append_parts' own, operation for operation (sum in split order from 0, round once, one rounding per torch op of
+// apply_rotary_pos_emb, lade/models/modeling_llama.py:321-346): q, the cache rows and therefore the attention output are bit-identical
+// to the two-launch form (tests/test_gpu_fused_rope.py).
+// One item = 8 + 8 values of one head row: columns i .. i+7 and their rotation partners i + D/2 ..
+// (the cos / sin tables of a rotary embedding are cat(freqs, freqs) - lade/models/modeling_llama.py:252 - so ONE 16-byte load per table
+// serves columns i .. i+7 and i + D/2 ..: the fused form requires such tables, include/lade_hip.h)
+template <int NPC> struct RopeItem { float4 va[NPC][2], vb[NPC][2]; u32x4 c1, s1; };
+
+template <int NPC, int D>
+__device__ __forceinline__ void rope_load(RopeItem<NPC>& it, const AttnK& a, size_t e0, int trow, int i) {
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {                                       // a partial beyond n_parts re-reads the last one (never added)
+        const float* pa = a.parts + (size_t)min(j, a.n_parts - 1) * a.part_stride + e0;
+        it.va[j][0] = *reinterpret_cast<const float4*>(pa);
+        it.va[j][1] = *reinterpret_cast<const float4*>(pa + 4);
+        it.vb[j][0] = *reinterpret_cast<const float4*>(pa + D / 2);
+        it.vb[j][1] = *reinterpret_cast<const float4*>(pa + D / 2 + 4);
+    }
+    const uint16_t* c = a.cos_tab + (size_t)trow * D + i;
+    const uint16_t* sn = a.sin_tab + (size_t)trow * D + i;
+    it.c1 = *reinterpret_cast<const u32x4*>(c);
+    it.s1 = *reinterpret_cast<const u32x4*>(sn);
+}
+
+__device__ __forceinline__ uint16_t half_of(const u32x4& v, int e) { return (uint16_t)(v[e >> 1] >> ((e & 1) * 16)); }
+
+template <typename T, int NPC>
+__device__ __forceinline__ void rope_apply(const RopeItem<NPC>& it, int n_parts, u32x4& o1, u32x4& o2) {
+    float a[8], b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = 0.f; b[e] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < NPC; ++j)
+        if (j < n_parts) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                a[4 * h2] += it.va[j][h2].x; a[4 * h2 + 1] += it.va[j][h2].y; a[4 * h2 + 2] += it.va[j][h2].z; a[4 * h2 + 3] += it.va[j][h2].w;
+                b[4 * h2] += it.vb[j][h2].x; b[4 * h2 + 1] += it.vb[j][h2].y; b[4 * h2 + 2] += it.vb[j][h2].z; b[4 * h2 + 3] += it.vb[j][h2].w;
+            }
+        }
+    uint16_t r1[8], r2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float a1 = Elem<T>::ld(Elem<T>::st(a[e])), a2 = Elem<T>::ld(Elem<T>::st(b[e]));
+        // q*cos + rotate_half(q)*sin, rotate_half = cat(-x2, x1); one rounding per torch op
+        r1[e] = Elem<T>::st(__fadd_rn(rnd<T>(__fmul_rn(a1, Elem<T>::ld(half_of(it.c1, e)))), rnd<T>(__fmul_rn(-a2, Elem<T>::ld(half_of(it.s1, e))))));
+        r2[e] = Elem<T>::st(__fadd_rn(rnd<T>(__fmul_rn(a2, Elem<T>::ld(half_of(it.c1, e)))), rnd<T>(__fmul_rn(a1, Elem<T>::ld(half_of(it.s1, e))))));
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        o1[e] = (uint32_t)r1[2 * e] | ((uint32_t)r1[2 * e + 1] << 16);
+        o2[e] = (uint32_t)r2[2 * e] | ((uint32_t)r2[2 * e + 1] << 16);
+    }
+}
+
 // Work split inside a work-group of RG x KQ waves: wave (rg, kq) owns query rows [32*rg, 32*rg+32) of the block and the
 // 32-key part kq of every stage; a stage is KQ/2 tiles of 64 keys.  Three shapes are built:
 //   RG=4, KQ=2 (8 waves, 128 rows, stage = 1 tile,  3-stage ring)   steps of more than 64 (head-in-group, token) rows
@@ -284,7 +355,8 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // KV split sp of n_splits takes a CONTIGUOUS range of ceil(tiles / n_splits) 64-key tiles (the interleaved assignment sp, sp+n, ...
 // is kept behind LADE_ATTN_DBG=64: it balances perfectly but loses DRAM locality, +1.6 us at the 7B shape).  The KQ key parts keep
 // separate online-softmax states and are merged through LDS at the end.
-template <typename T, int D, int RG, int KQ>
+// NPC = 0: q is read from memory and the new K / V rows are already in the cache; NPC = 2 | 4: fused RoPE + KV append from up to NPC partials
+template <typename T, int D, int RG, int KQ, int NPC>
 __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
     constexpr int NW = RG * KQ;                    // waves
     constexpr int NTHR = 64 * NW;
@@ -334,20 +406,48 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
     };
     // the Q tile is requested FIRST: its addresses need nothing but the block id, so its pieces are on their way while the cache length
     // (a dependent scalar load in hipGraph steps) is still in flight; the first counted wait covers the Q tile + stage 0 (Q is the oldest)
+    constexpr int VPH = D / 16;                    // fused: 16-byte vector pairs (i, i + D/2) of one head row
+    constexpr int NPI = NPC ? NPC : 1;
+    constexpr int QI = (ROWS * VPH + NTHR - 1) / NTHR;       // fused: rope items of the Q tile per thread
+    RopeItem<NPI> qit[QI];
+    auto q_item = [&](int it, int& row, int& i, int& hg, int& t) -> int {      // 0: nothing, 1: a real row, 2: a padding row of a live 32-row group (zeros)
+        const int idx = tid + it * NTHR;
+        row = idx / VPH;
+        i = (idx - row * VPH) * 8;
+        hg = 0; t = 0;
+        if (idx >= ROWS * VPH) return 0;
+        const int r = rbk * ROWS + row;
+        if (r < n_rows) { split_row(r, hg, t); return 1; }
+        return rbk * ROWS + (row & ~31) < n_rows ? 2 : 0;
+    };
+    if constexpr (NPC == 0) {
 #pragma unroll
-    for (int i = 0; i < QPW; ++i) {
-        const int piece = wave * QPW + i;
-        // a 32-row group without any row (a steady 7B step has 60 rows: groups 2 and 3 of the 128-row block) is not requested at all:
-        // its waves never read it (wave_rows below).  Pieces are wave uniform, the counted waits below do not depend on how many a wave issued.
-        if (rbk * ROWS + (piece * (64 / K_CPR) / 32) * 32 >= n_rows) continue;
-        const int row = piece * (64 / K_CPR) + lane / K_CPR;
-        const int c = (lane % K_CPR) ^ swz16<2 * D>(row);
-        int r = rbk * ROWS + row, hg, t;
-        if (r >= n_rows) r = 0;                       // rows past the end read row 0; never stored
-        split_row(r, hg, t);
-        const uint16_t* src = a.q + (size_t)t * a.q_row_stride + (size_t)(kvh * n_rep + hg) * D + c * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(q_lds + piece * 1024), 16, 0, 0);
+        for (int i = 0; i < QPW; ++i) {
+            const int piece = wave * QPW + i;
+            // a 32-row group without any row (a steady 7B step has 60 rows: groups 2 and 3 of the 128-row block) is not requested at all:
+            // its waves never read it (wave_rows below).  Pieces are wave uniform, the counted waits below do not depend on how many a wave issued.
+            if (rbk * ROWS + (piece * (64 / K_CPR) / 32) * 32 >= n_rows) continue;
+            const int row = piece * (64 / K_CPR) + lane / K_CPR;
+            const int c = (lane % K_CPR) ^ swz16<2 * D>(row);
+            int r = rbk * ROWS + row, hg, t;
+            if (r >= n_rows) r = 0;                       // rows past the end read row 0; never stored
+            split_row(r, hg, t);
+            const uint16_t* src = a.q + (size_t)t * a.q_row_stride + (size_t)(kvh * n_rep + hg) * D + c * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(q_lds + piece * 1024), 16, 0, 0);
+        }
+    } else {
+        // fused: the q rows of this block as fp32 partials of the qkv projection + their cos / sin rows, requested before anything that
+        // depends on the cache length; rotated and written to the Q tile further down, behind the K / V requests
+#pragma unroll
+        for (int it = 0; it < QI; ++it) {
+            int row, i, hg, t;
+            if (q_item(it, row, i, hg, t) == 1) {
+                int trow = t;
+                if (a.positions) { trow = a.positions[t]; trow = trow < 0 ? 0 : (trow >= a.max_pos ? a.max_pos - 1 : trow); }
+                rope_load<NPI, D>(qit[it], a, (size_t)t * a.row_w + (size_t)(kvh * n_rep + hg) * D + i, trow, i);
+            }
+        }
     }
     // ---- split geometry: split sp covers the 64-key tiles base, base+stride, ... (my_tiles of them)
     lade_mask_params m = a.m;
@@ -362,15 +462,11 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
         const int tmax = hg0 != hg1 ? m.T - 1 : r1 - hg1 * m.T;
         n_tiles = min(n_tiles, (m.P + tmax + 1 + KT - 1) / KT);
     }
-    int base, stride, my_tiles;
-    if (a.dbg & 64) {                               // interleaved: splits differ by at most one tile
-        base = sp; stride = ns;
-        my_tiles = sp < n_tiles ? (int)div_magic((uint32_t)(n_tiles - sp + ns - 1), a.ns_magic) : 0;
-    } else {                                        // contiguous key ranges
-        const int tps = (int)div_magic((uint32_t)(n_tiles + ns - 1), a.ns_magic);       // no integer division on the way to the first DMA
-        base = sp * tps; stride = 1;
-        my_tiles = max(0, min(base + tps, n_tiles) - base);
-    }
+    // contiguous key ranges (an interleaved assignment sp, sp + n, .. balances perfectly but loses DRAM locality: +1.6 us at the 7B shape, round 2)
+    const int tps = (int)div_magic((uint32_t)(n_tiles + ns - 1), a.ns_magic);       // no integer division on the way to the first DMA
+    const int base = sp * tps;
+    constexpr int stride = 1;
+    const int my_tiles = max(0, min(base + tps, n_tiles) - base);
     // ---- LDS-DMA (no VGPR staging): the split's first NSTG stages are requested before the row bookkeeping; a tile that lies
     // beyond the split is a harmless read inside the cache allocation (an L2 hit of the split's first tile) and is never computed on
     const int last_tile = a.S_max / KT - 1;
@@ -413,15 +509,6 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
                                              (__attribute__((address_space(3))) void*)(vs + piece * 1024), 16, 0, 0);
         }
     };
-#pragma unroll
-    for (int ts = 0; ts < TPS; ++ts) issue_tiles(0, ts, ts < my_tiles ? base + ts * stride : base);
-
-#pragma unroll
-    for (int s = 1; s < NSTG; ++s)
-#pragma unroll
-        for (int ts = 0; ts < TPS; ++ts) issue_tiles(s, ts, s * TPS + ts < my_tiles ? base + (s * TPS + ts) * stride : base);
-    dbg_stamp(a, 1);
-
     const int nt = (my_tiles + TPS - 1) / TPS;                                  // stages
     const int nt_issued = max(nt, NSTG);                                        // the first NSTG stages are always in flight
     // global index (64-key units) of tile ts of stage j; a stage's missing second tile re-reads the split's first tile (an L2
@@ -431,6 +518,135 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
 #pragma unroll
         for (int ts = 0; ts < TPS; ++ts) issue_tiles(stage, ts, tile_of(j, ts));
     };
+    int store_fence_at = -1;             // fused: the loop iteration behind which the first tile holding a row this work-group stored is requested
+    if constexpr (NPC == 0) {
+#pragma unroll
+        for (int s = 0; s < NSTG; ++s) issue_stage(s, s);
+    } else {
+        // ---- fused RoPE + KV append ----
+        // the rows P .. P+T of K and V^T that fall into this work-group's key range are its own to produce: key k_lo .. k_hi
+        const int k_lo = max(m.P, base * KT), k_hi = min(S_tot, (base + my_tiles) * KT);
+        const int n_new = S_tot <= a.S_max ? max(0, k_hi - k_lo) : 0;         // (a device-side cache length past the cache: nothing is written, as in lade_rope_kv_append)
+        const int t_lo = k_lo - m.P;
+        auto q_finish = [&]() {                  // rotate the q rows and write them to the Q tile (swizzled like the DMA would have)
+#pragma unroll
+            for (int it = 0; it < QI; ++it) {
+                int row, i, hg, t;
+                const int kind = q_item(it, row, i, hg, t);
+                if (kind == 0) continue;
+                u32x4 o1 = u32x4{0u, 0u, 0u, 0u}, o2 = o1;
+                if (kind == 1) rope_apply<T, NPI>(qit[it], a.n_parts, o1, o2);
+                *reinterpret_cast<u32x4*>(q_lds + tile_off<2 * D>(row, i >> 3)) = o1;
+                *reinterpret_cast<u32x4*>(q_lds + tile_off<2 * D>(row, (i + D / 2) >> 3)) = o2;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // published by the barrier of the loop's first iteration
+        };
+        if (n_new == 0) {
+#pragma unroll
+            for (int s = 0; s < NSTG; ++s) issue_stage(s, s);
+            q_finish();
+        } else {
+            constexpr int CH = 16 * RG;                      // new K / V rows per pass
+            constexpr int KI = (CH * VPH + NTHR - 1) / NTHR; // rope items of a pass per thread
+            constexpr int VS = CH * (D / 4) / NTHR;          // float4 sites of a pass's V rows per thread
+            constexpr int LDV = D + 2;                       // row stride (elements) of the V staging tile [CH][D]: it lives in the Q tile
+            static_assert(VS >= 1 && (CH * (D / 4)) % NTHR == 0 && CH * LDV * 2 <= Q_BYTES, "V staging pass");
+            const size_t k_col = (size_t)(a.H + kvh) * D, v_col = (size_t)(a.H + a.Hkv + kvh) * D;
+            RopeItem<NPI> kit[KI];
+            float4 vpart[NPI][VS];
+            auto kv_load = [&](int c) {
+#pragma unroll
+                for (int it = 0; it < KI; ++it) {
+                    const int idx = tid + it * NTHR, tt = idx / VPH, i = (idx - tt * VPH) * 8;
+                    if (idx < CH * VPH && c * CH + tt < n_new) {
+                        const int t = t_lo + c * CH + tt;
+                        int trow = t;
+                        if (a.positions) { trow = a.positions[t]; trow = trow < 0 ? 0 : (trow >= a.max_pos ? a.max_pos - 1 : trow); }
+                        rope_load<NPI, D>(kit[it], a, (size_t)t * a.row_w + k_col + i, trow, i);
+                    }
+                }
+#pragma unroll
+                for (int sv = 0; sv < VS; ++sv) {
+                    const int idx = tid + sv * NTHR, tt = idx / (D / 4), d4 = (idx - tt * (D / 4)) * 4;
+                    if (c * CH + tt < n_new) {
+                        const size_t e0 = (size_t)(t_lo + c * CH + tt) * a.row_w + v_col + d4;
+#pragma unroll
+                        for (int j = 0; j < NPI; ++j) vpart[j][sv] = *reinterpret_cast<const float4*>(a.parts + (size_t)min(j, a.n_parts - 1) * a.part_stride + e0);
+                    }
+                }
+            };
+            auto kv_store = [&](int c, uint16_t* stage_v) {
+                // V: partials summed in split order, rounded once, staged [token][d] ...
+#pragma unroll
+                for (int sv = 0; sv < VS; ++sv) {
+                    const int idx = tid + sv * NTHR, tt = idx / (D / 4), d4 = (idx - tt * (D / 4)) * 4;
+                    if (c * CH + tt < n_new) {
+                        float4 acc = float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int j = 0; j < NPI; ++j)
+                            if (j < a.n_parts) { acc.x += vpart[j][sv].x; acc.y += vpart[j][sv].y; acc.z += vpart[j][sv].z; acc.w += vpart[j][sv].w; }
+                        uint32_t* dst = reinterpret_cast<uint32_t*>(stage_v + tt * LDV + d4);
+                        dst[0] = (uint32_t)from_f32<T>(acc.x) | ((uint32_t)from_f32<T>(acc.y) << 16);
+                        dst[1] = (uint32_t)from_f32<T>(acc.z) | ((uint32_t)from_f32<T>(acc.w) << 16);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wg_barrier();
+                // K: rotated rows straight to cache row P + t
+#pragma unroll
+                for (int it = 0; it < KI; ++it) {
+                    const int idx = tid + it * NTHR, tt = idx / VPH, i = (idx - tt * VPH) * 8;
+                    if (idx < CH * VPH && c * CH + tt < n_new) {
+                        u32x4 o1, o2;
+                        rope_apply<T, NPI>(kit[it], a.n_parts, o1, o2);
+                        uint16_t* dst = a.k_w + ((size_t)kvh * a.S_max + k_lo + c * CH + tt) * D + i;
+                        *reinterpret_cast<u32x4*>(dst) = o1;
+                        *reinterpret_cast<u32x4*>(dst + D / 2) = o2;
+                    }
+                }
+                // ... and written transposed, the token index fastest: V^T[d][P + t]
+                for (int idx = tid; idx < D * CH; idx += NTHR) {
+                    const int dd = idx / CH, tt = idx - dd * CH;
+                    if (c * CH + tt < n_new) a.vt_w[((size_t)kvh * D + dd) * a.S_max + k_lo + c * CH + tt] = stage_v[tt * LDV + dd];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wg_barrier();                  // the staging tile is free again (next pass, or the q rows)
+            };
+            // the stages that hold none of those rows are requested now, the others once the rows are in memory
+            const int first_new_q = m.P / KT - base;       // tile (within the split) of the first new key; <= 0: the split starts inside the new rows
+            int early = 0;
+#pragma unroll
+            for (int s = 0; s < NSTG; ++s) {
+                const int last_q = s * TPS < my_tiles ? min(s * TPS + TPS - 1, my_tiles - 1) : 0;
+                if (early == s && last_q < first_new_q) early = s + 1;
+            }
+            const int n_pass = (n_new + CH - 1) / CH;
+            if (early == NSTG) {
+                // the usual case: the new rows lie behind the first NSTG stages.  Straight-line code: the partials are requested BEFORE the
+                // stages, so the counted wait the compiler derives for them leaves every DMA piece in flight.  The V staging tile lives in
+                // the Q tile, which is written last.
+                kv_load(0);
+#pragma unroll
+                for (int s = 0; s < NSTG; ++s) issue_stage(s, s);
+                kv_store(0, reinterpret_cast<uint16_t*>(q_lds));
+                for (int c = 1; c < n_pass; ++c) { kv_load(c); kv_store(c, reinterpret_cast<uint16_t*>(q_lds)); }
+                q_finish();
+                // the stores must have landed before the first stage that holds one of those rows is requested: checked in the loop, where
+                // that request is made (a wait here would also wait for the stages in flight)
+                store_fence_at = max(NSTG, first_new_q / TPS) - NSTG;
+            } else {
+                // a split that reaches the new rows within its first NSTG stages (short caches): nothing is requested before the rows are in
+                // memory; the q rows go first (their registers are free for the passes), the V staging tile lives in the idle ring
+                q_finish();
+                for (int c = 0; c < n_pass; ++c) { kv_load(c); kv_store(c, reinterpret_cast<uint16_t*>(smem)); }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                wg_barrier();
+#pragma unroll
+                for (int s = 0; s < NSTG; ++s) issue_stage(s, s);
+            }
+        }
+    }
+    dbg_stamp(a, 1);
 
     // this lane's query row (overlaps the DMA flight)
     const int r = rbk * ROWS + rg * 32 + ql;
@@ -559,6 +775,11 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
         }
         if (i + NSTG < nt) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (NPC > 0) {
+                // fused: this work-group's own K / V rows have reached memory before a stage that holds them is requested (once per launch,
+                // work-group uniform; every wave waits for its own stores, the barrier covers the others')
+                if (i == store_fence_at) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             wg_barrier();              // every wave is done reading this stage
             issue_stage(i + NSTG, stage);
         }
@@ -789,13 +1010,21 @@ __global__ __launch_bounds__(64) void attn_fwd_f32_kernel(AttnF32 a) {
 
 static int validate(const lade_attn_args* a) {
     LADE_REQUIRE(a != nullptr, LADE_E_ARG, "lade_attn: null args");
-    LADE_REQUIRE(a->q && a->k_cache && a->vt_cache && a->out, LADE_E_ARG, "lade_attn: null tensor pointer");
+    LADE_REQUIRE((a->q || a->n_parts != 0) && a->k_cache && a->vt_cache && a->out, LADE_E_ARG, "lade_attn: null tensor pointer");
     LADE_REQUIRE(a->H > 0 && a->Hkv > 0 && a->H % a->Hkv == 0, LADE_E_ARG, "lade_attn: H=%d Hkv=%d", a->H, a->Hkv);
     LADE_REQUIRE(a->mask.T > 0 && a->mask.P >= 0, LADE_E_ARG, "lade_attn: T=%d P=%d", a->mask.T, a->mask.P);
     LADE_REQUIRE(a->S_max % 64 == 0 && a->mask.P + a->mask.T <= a->S_max, LADE_E_ARG,
                  "lade_attn: S_max=%d must be a multiple of 64 and >= P+T=%d", a->S_max, a->mask.P + a->mask.T);
     LADE_REQUIRE(a->n_splits >= 1 && a->n_splits <= 32, LADE_E_ARG, "lade_attn: n_splits=%d (1..32)", a->n_splits);
     LADE_REQUIRE(a->n_splits == 1 || (a->part_o && a->part_ml), LADE_E_ARG, "lade_attn: split-KV needs partial buffers");
+    LADE_REQUIRE(a->wg_rows == 0 || a->wg_rows == 32 || a->wg_rows == 64 || a->wg_rows == 128, LADE_E_ARG, "lade_attn: wg_rows=%d (0, 32, 64, 128)", a->wg_rows);
+    if (a->n_parts != 0) {
+        LADE_REQUIRE(a->n_parts >= 1 && a->n_parts <= 4, LADE_E_LIMIT, "lade_attn: fused RoPE takes 1..4 split-K partials, got %d", a->n_parts);
+        LADE_REQUIRE(a->qkv_parts && a->cos_tab && a->sin_tab && a->max_pos > 0, LADE_E_ARG, "lade_attn: fused RoPE needs qkv_parts, cos_tab, sin_tab, max_pos");
+        LADE_REQUIRE(a->positions || a->max_pos >= a->mask.T, LADE_E_ARG, "lade_attn: fused RoPE without positions reads table rows 0..T-1 (max_pos=%d, T=%d)", a->max_pos, a->mask.T);
+        LADE_REQUIRE(a->dtype == LADE_BF16 || a->dtype == LADE_F16, LADE_E_DTYPE, "lade_attn: fused RoPE is built for bf16 / f16 (dtype=%d)", a->dtype);
+        LADE_REQUIRE(a->part_stride >= (int64_t)a->mask.T * (a->H + 2 * a->Hkv) * a->d, LADE_E_ARG, "lade_attn: part_stride %lld is shorter than one partial", (long long)a->part_stride);
+    }
     if (!a->mask.is_prefill) {
         const lade_mask_params& m = a->mask;
         LADE_REQUIRE(m.s >= 0 && m.gs > 0 && m.lguess >= 0 && m.lguess % m.gs == 0 && m.level_offset >= 0 && m.dist_offset >= 0,
@@ -825,10 +1054,14 @@ static AttnK make_k(const lade_attn_args* a) {
     k.scale_log2 = a->scale * 1.4426950408889634f;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("LADE_ATTN_DBG"); dbg = e ? atoi(e) : 0; } k.dbg = dbg; }
     k.m = a->mask;
+    k.parts = a->qkv_parts; k.part_stride = (size_t)a->part_stride; k.positions = a->positions;
+    k.cos_tab = (const uint16_t*)a->cos_tab; k.sin_tab = (const uint16_t*)a->sin_tab;
+    k.k_w = (uint16_t*)a->k_cache; k.vt_w = (uint16_t*)a->vt_cache;
+    k.n_parts = a->n_parts; k.max_pos = a->max_pos; k.row_w = (a->H + 2 * a->Hkv) * a->d;
     return k;
 }
 
-template <typename T, int D, int RG, int KQ>
+template <typename T, int D, int RG, int KQ, int NPC>
 static int launch_fwd_shape(const lade_attn_args* a, hipStream_t st) {
     AttnK k = make_k(a);
     const int n_rep = a->H / a->Hkv;
@@ -838,26 +1071,33 @@ static int launch_fwd_shape(const lade_attn_args* a, hipStream_t st) {
     const size_t lds = (size_t)KT * D * 2 * 2 * TPS * NSTG + (size_t)ROWS * D * 2;
     static bool attr_set = false;          // > 64 KiB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, RG, KQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, RG, KQ, NPC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((attn_fwd_kernel<T, D, RG, KQ>), grid, dim3(64 * RG * KQ), lds, st, k);
+    hipLaunchKernelGGL((attn_fwd_kernel<T, D, RG, KQ, NPC>), grid, dim3(64 * RG * KQ), lds, st, k);
     return check_launch("lade_attn_fwd");
 }
 
-// rows = (heads per KV head) x T of one KV head pick the work-group shape (LADE_ATTN_SHAPE = 128 | 64 | 32 forces one: experiments)
-template <typename T, int D>
-static int launch_fwd(const lade_attn_args* a, hipStream_t st) {
+// The work-group shape is a launch parameter (lade_attn_args.wg_rows: 128 | 64 | 32 query rows of the (head-in-group, token) space per
+// work-group; 0 = 128): which one is fastest depends on the rows per KV head, the split count and the cache length, so the caller's autotune
+// decides it per launch shape inside a step, like the GEMM configurations (StepEngine._refine_attn).  LADE_ATTN_SHAPE forces one (experiments).
+template <typename T, int D, int NPC>
+static int launch_fwd_npc(const lade_attn_args* a, hipStream_t st) {
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("LADE_ATTN_SHAPE"); forced = e ? atoi(e) : 0; }
-    const int rows = (a->H / a->Hkv) * a->mask.T;
-    // measured (T = 60, P = 2016, 7B heads): the 64-row shape (every wave computes, three key parts to merge) is 0.4-1.0 us slower
-    // than the 128-row shape whose idle row groups only move DMA pieces, so the 128-row shape is the default for every step
-    (void)rows;
-    const int shape = forced ? forced : 128;
-    if (shape == 32) return launch_fwd_shape<T, D, 1, 4>(a, st);
-    if (shape == 64) return launch_fwd_shape<T, D, 2, 4>(a, st);
-    return launch_fwd_shape<T, D, 4, 2>(a, st);
+    const int shape = forced ? forced : (a->wg_rows ? a->wg_rows : 128);
+    if (shape == 32) return launch_fwd_shape<T, D, 1, 4, NPC>(a, st);
+    // (fused RoPE from 3 or 4 partials: two q items of four partials each + a pass of K / V rows do not fit the 128-row shape's
+    // register file - 359 spilled registers -, so a 128-row request runs as 64-row blocks)
+    if (shape == 64 || NPC > 2) return launch_fwd_shape<T, D, 2, 4, NPC>(a, st);
+    if constexpr (NPC <= 2) return launch_fwd_shape<T, D, 4, 2, NPC>(a, st);
+    return LADE_E_LIMIT;
+}
+
+template <typename T, int D>
+static int launch_fwd(const lade_attn_args* a, hipStream_t st) {
+    if (a->n_parts == 0) return launch_fwd_npc<T, D, 0>(a, st);
+    return a->n_parts <= 2 ? launch_fwd_npc<T, D, 2>(a, st) : launch_fwd_npc<T, D, 4>(a, st);
 }
 
 }  // namespace lade
@@ -883,7 +1123,7 @@ extern "C" int lade_attn_fwd(const lade_attn_args* a, void* stream) {
     }
     LADE_REQUIRE(a->dtype == LADE_BF16 || a->dtype == LADE_F16, LADE_E_DTYPE, "lade_attn_fwd: dtype=%d", a->dtype);
     LADE_REQUIRE(a->d == 128 || a->d == 64, LADE_E_DTYPE, "lade_attn_fwd: head_dim %d (MFMA kernel supports 64 and 128)", a->d);
-    LADE_REQUIRE(a->q_row_stride % 8 == 0 && a->out_row_stride % 8 == 0, LADE_E_ARG, "lade_attn_fwd: row strides must keep 16-B alignment");
+    LADE_REQUIRE((a->n_parts != 0 || a->q_row_stride % 8 == 0) && a->out_row_stride % 8 == 0, LADE_E_ARG, "lade_attn_fwd: row strides must keep 16-B alignment");
     if (a->dtype == LADE_BF16) return a->d == 128 ? launch_fwd<BF16, 128>(a, st) : launch_fwd<BF16, 64>(a, st);
     return a->d == 128 ? launch_fwd<F16, 128>(a, st) : launch_fwd<F16, 64>(a, st);
 }

@@ -78,4 +78,21 @@ __device__ __forceinline__ uint32_t pack2<F16>(float lo, float hi) {
     return (uint32_t)from_f32<F16>(lo) | ((uint32_t)from_f32<F16>(hi) << 16);
 }
 
+// storage-type helpers: 16-bit types round after every elementwise op exactly like torch does
+// (fp32 math, one rounding per op); fp32 uses separately rounded mul / add (no contraction).
+template <typename T> struct Elem;
+template <> struct Elem<BF16> { typedef uint16_t S; __device__ static float ld(S v) { return to_f32<BF16>(v); } __device__ static S st(float f) { return from_f32<BF16>(f); } };
+template <> struct Elem<F16> { typedef uint16_t S; __device__ static float ld(S v) { return to_f32<F16>(v); } __device__ static S st(float f) { return from_f32<F16>(f); } };
+template <> struct Elem<F32> { typedef float S; __device__ static float ld(S v) { return v; } __device__ static S st(float f) { return f; } };
+
+// one rounding to the storage type.  The empty asm keeps the compiler from narrowing the fp32
+// expression to native f16 ops and contracting mul+add into v_fma_f16, which would skip a rounding
+// the reference's separate torch ops perform.
+template <typename T>
+__device__ __forceinline__ float rnd(float f) {
+    float r = Elem<T>::ld(Elem<T>::st(f));
+    asm volatile("" : "+v"(r));
+    return r;
+}
+
 }  // namespace lade

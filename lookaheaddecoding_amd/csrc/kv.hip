@@ -11,23 +11,6 @@
 
 namespace lade {
 
-// storage-type helpers: 16-bit types round after every elementwise op exactly like torch does
-// (fp32 math, one rounding per op); fp32 uses separately rounded mul / add (no contraction).
-template <typename T> struct Elem;
-template <> struct Elem<BF16> { typedef uint16_t S; __device__ static float ld(S v) { return to_f32<BF16>(v); } __device__ static S st(float f) { return from_f32<BF16>(f); } };
-template <> struct Elem<F16> { typedef uint16_t S; __device__ static float ld(S v) { return to_f32<F16>(v); } __device__ static S st(float f) { return from_f32<F16>(f); } };
-template <> struct Elem<F32> { typedef float S; __device__ static float ld(S v) { return v; } __device__ static S st(float f) { return f; } };
-
-// one rounding to the storage type.  The empty asm keeps the compiler from narrowing the fp32
-// expression to native f16 ops and contracting mul+add into v_fma_f16, which would skip a rounding
-// the reference's separate torch ops perform.
-template <typename T>
-__device__ __forceinline__ float rnd(float f) {
-    float r = Elem<T>::ld(Elem<T>::st(f));
-    asm volatile("" : "+v"(r));
-    return r;
-}
-
 // One launch does both halves of the append.
 //   blocks [0, T*bpt)       : token t (bpt blocks per token).  q rotated in place, rotated k -> K cache row P+t.
 //                             A thread owns VEC consecutive pairs (i, i+d/2) of one head: 16-byte loads / stores.
@@ -207,6 +190,32 @@ __global__ __launch_bounds__(256) void kv_commit_kernel(S* cache, int64_t layer_
     }
 }
 
+// K / V as the reference hands them to its flash kernel - [S][Hkv][d], token-major (modeling_llama.py:705-713 after the
+// transposes of :636-638) - re-laid into this library's cache layout: K [Hkv][S_max][d], V^T [Hkv][d][S_max].
+// grid (ceil(S / 64), Hkv): the block copies its 64 K rows as 16-byte vectors and transposes its 64 x d slab of V through LDS
+// so that both sides of the transpose move whole 128-byte runs.
+template <typename S>
+__global__ __launch_bounds__(256) void kv_pack_bshd_kernel(const S* k, const S* v, S* k_cache, S* vt_cache, int S_tot, int Hkv, int d, int S_max,
+                                                           int64_t tok_stride, int64_t head_stride) {
+    constexpr int VEC = 16 / sizeof(S);
+    extern __shared__ __attribute__((aligned(16))) unsigned char pack_smem[];
+    S* sm = reinterpret_cast<S*>(pack_smem);                 // [64][d + VEC] (padded rows)
+    const int s0 = blockIdx.x * 64, h = blockIdx.y;
+    const int ns = min(64, S_tot - s0);
+    const int cpr = d / VEC, ldr = d + VEC;
+    for (int idx = threadIdx.x; idx < ns * cpr; idx += blockDim.x) {
+        const int r = idx / cpr, c = (idx - r * cpr) * VEC;
+        const size_t src = (size_t)(s0 + r) * tok_stride + (size_t)h * head_stride + c;
+        *reinterpret_cast<uint4*>(k_cache + ((size_t)h * S_max + s0 + r) * d + c) = *reinterpret_cast<const uint4*>(k + src);
+        *reinterpret_cast<uint4*>(sm + r * ldr + c) = *reinterpret_cast<const uint4*>(v + src);
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < d * 64; idx += blockDim.x) {
+        const int dd = idx >> 6, r = idx & 63;
+        if (r < ns) vt_cache[((size_t)h * d + dd) * S_max + s0 + r] = sm[r * ldr + dd];
+    }
+}
+
 template <typename T>
 static int launch_rope(void* qkv, const int32_t* positions, const void* cos_tab, const void* sin_tab, void* k_cache,
                        void* vt_cache, int T_, int P, const int32_t* dyn_P, int H, int Hkv, int d, int S_max, int max_pos,
@@ -303,6 +312,25 @@ extern "C" int lade_kv_commit(void* cache, int64_t layer_stride, int64_t v_offse
     else
         hipLaunchKernelGGL(kv_commit_kernel<uint32_t>, dim3(L, Hkv), dim3(256), 0, st, (uint32_t*)cache, layer_stride, v_offset, Hkv, d, S_max, src, dst, cnt, ctl);
     return check_launch("lade_kv_commit");
+}
+
+extern "C" int lade_kv_pack_bshd(const void* k, const void* v, int64_t tok_stride, int64_t head_stride, void* k_cache, void* vt_cache, int32_t S,
+                                 int32_t Hkv, int32_t d, int32_t S_max, int32_t elem_bytes, void* stream) {
+    LADE_REQUIRE(k && v && k_cache && vt_cache, LADE_E_ARG, "lade_kv_pack_bshd: null pointer");
+    LADE_REQUIRE(S > 0 && Hkv > 0 && d > 0 && d <= 256 && S <= S_max, LADE_E_ARG, "lade_kv_pack_bshd: S=%d Hkv=%d d=%d S_max=%d", S, Hkv, d, S_max);
+    LADE_REQUIRE(elem_bytes == 2 || elem_bytes == 4, LADE_E_DTYPE, "lade_kv_pack_bshd: elem_bytes=%d", elem_bytes);
+    LADE_REQUIRE((d * elem_bytes) % 16 == 0 && (tok_stride * elem_bytes) % 16 == 0 && (head_stride * elem_bytes) % 16 == 0 && tok_stride > 0 && head_stride > 0,
+                 LADE_E_ARG, "lade_kv_pack_bshd: head rows and strides must be multiples of 16 bytes (d=%d strides %lld %lld)", d, (long long)tok_stride, (long long)head_stride);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)64 * (d + 16 / elem_bytes) * elem_bytes;
+    const dim3 grid(cdiv(S, 64), Hkv);
+    if (elem_bytes == 2) {
+        hipLaunchKernelGGL(kv_pack_bshd_kernel<uint16_t>, grid, dim3(256), lds, st, (const uint16_t*)k, (const uint16_t*)v, (uint16_t*)k_cache, (uint16_t*)vt_cache, S, Hkv, d, S_max, tok_stride, head_stride);
+    } else {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kv_pack_bshd_kernel<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kv_pack_bshd_kernel<uint32_t>, grid, dim3(256), lds, st, (const uint32_t*)k, (const uint32_t*)v, (uint32_t*)k_cache, (uint32_t*)vt_cache, S, Hkv, d, S_max, tok_stride, head_stride);
+    }
+    return check_launch("lade_kv_pack_bshd");
 }
 
 // qkv arrives as n_parts fp32 split-K partials [n_parts][T][(H+2Hkv)*d]; the rotated q goes to q_out [T][H*d]

@@ -11,6 +11,8 @@ from __future__ import annotations
 
 import os
 import random
+import sys
+import time
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
@@ -81,18 +83,28 @@ class LadeState:
         torch.cuda.current_stream().synchronize()
         return self.record_host.tolist()
 
-    def poll_record(self, step_no: int, spin_limit: int = 2_000_000) -> Optional[List[int]]:
+    POLL_TIMEOUT_S = float(os.environ.get("LADE_POLL_TIMEOUT_MS", "250")) * 1e-3
+
+    def poll_record(self, step_no: int, timeout_s: Optional[float] = None) -> Optional[List[int]]:
         """The record of step `step_no` as `lade_greedy_post_step` stored it into the pinned host buffer (mapped into the device: no
         copy node, no stream synchronisation).  The host spins on the buffer until the record carries that step number and its seal
-        (`lade_record_seal` over the other words) matches what was read - a stale or half-landed record fails one of the two.
-        None when the record does not arrive within the spin limit (the caller then synchronises the stream and reads it the slow way)."""
+        (`lade_record_seal` over the other words) matches what was read - a stale or half-landed record fails one of the two; the seal is
+        the ONLY ordering guarantee (the kernel issues no system-scope fence behind the stores).
+        The spin is bounded by WALL-CLOCK time (LADE_POLL_TIMEOUT_MS, default 250 ms - far beyond any step) and yields the GIL every 256
+        reads, so that a streamer thread or lookahead-parallel rank threads of this process are not starved while this one waits.  None
+        when the record does not arrive in time - e.g. pinned memory the device's stores do not reach coherently (HIP_HOST_COHERENT=0);
+        the caller then synchronises the stream, reads the record the slow way and STOPS polling for good (LookaheadDecoder._step_graph)."""
         buf = self.record_host_np
-        for _ in range(spin_limit):
-            if buf[7] == step_no:
-                rec = buf.tolist()
-                if rec[7] == step_no and (rec[REC_WORDS - 1] & 0xFFFFFFFF) == record_seal(rec, step_no):
-                    return rec
-        return None
+        deadline = time.monotonic() + (self.POLL_TIMEOUT_S if timeout_s is None else timeout_s)
+        while True:
+            for _ in range(256):
+                if buf[7] == step_no:
+                    rec = buf.tolist()
+                    if rec[7] == step_no and (rec[REC_WORDS - 1] & 0xFFFFFFFF) == record_seal(rec, step_no):
+                        return rec
+            if time.monotonic() > deadline:
+                return None
+            time.sleep(0)                      # release the GIL: other threads of the process get to run
 
 
 class LookaheadDecoder:
@@ -115,6 +127,10 @@ class LookaheadDecoder:
         self.st = LadeState(engine.V, W, N, G, engine.device, engine.max_T)
         if self.max_step_tokens() > engine.max_T:
             raise cabi.LadeHipError(f"W={W} N={N} G={G} needs {self.max_step_tokens()} tokens per step > engine.max_T={engine.max_T}")
+        # every kernel decision the steady steps of this configuration need (GEMM shapes, the in-step pass, the attention launch
+        # parameters) is taken NOW, not inside the first live step of each row class (a multi-second stall for that request)
+        if lp is None and os.environ.get("LADE_PREPARE", "1") != "0":
+            engine.prepare(sorted({(N - 1) * (W + b) for b in self._buckets()}))
 
     def max_step_tokens(self) -> int:
         return self.gs + (self.N - 1) * self.W + self.G * self.gs
@@ -270,8 +286,14 @@ class LookaheadDecoder:
         rec = st.poll_record(self._step_no + 1) if self.poll else None
         if rec is None:
             torch.cuda.current_stream().synchronize()
-            if self.poll:                          # the record never arrived through the mapped buffer: read the device copy
+            if self.poll:
+                # the record never arrived through the mapped buffer: read the device copy, and stop polling for good - every later step
+                # would pay the same time-out.  The graphs are re-captured with the copy node instead of the mapped store.
                 rec = st.read_record()
+                self.poll = False
+                self._graph = None
+                print("[lade] the step record did not arrive through the host-mapped buffer within the polling time-out: "
+                      "falling back to stream synchronisation for this decoder", file=sys.stderr, flush=True)
             else:
                 rec = st.record_host.tolist()
         self._step_no = rec[7]

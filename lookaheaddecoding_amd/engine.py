@@ -162,13 +162,18 @@ class StepEngine:
         self._alloc_cache(self.S_max)
         self.attn_events = None             # set to a list to collect (start, end, T, n_splits) hipEvent pairs per layer
         self.attn_events_empty = None       # ... and back-to-back event pairs (what an empty bracket reads)
-        self.skip_attn = False              # bench.py only: leave the attention launches out (step-time difference = their cost)
+        self.skip_attn = False              # bench.py only: True = leave the attention launches out, RoPE + KV append as a launch of their own (step-time
+                                            # difference = what attention costs on top of them); "all" = leave out RoPE + append as well
         self.max_splits = 32
         self.gemm_cfg = {}
         self.gemm_times = {}                # (projection, row class) -> (ms of the chosen kernel in the autotune, weight bytes)
         self._ranked = {}                   # (projection, row class) -> the isolated pass's candidates, fastest first [(ms, cfg | None)]
         self._refined = set()               # row classes whose decisions were re-taken inside the step (_refine_in_step)
         self._refining = False
+        # attention launch parameters per row class: (RoPE + KV append fused into the launch, work-group rows, split mode of ops.choose_splits);
+        # the default until (unless) the in-step pass decides: LADE_FUSE_ROPE (default 1), the 128-row shape, the sqrt split rule
+        self.attn_cfg = {}
+        self.attn_default = (1 if os.environ.get("LADE_FUSE_ROPE", "1") != "0" else 0, 128, 0)
         self.step_tune_log = {}             # row class -> what the in-step pass measured (bench.py prints it)
         self._alloc_workspaces(max_T)
         try:
@@ -387,7 +392,22 @@ class StepEngine:
                   nt["inv_tab"].shape[0], self.d, cabi.ptr(cos_r), cabi.ptr(sin_r), cabi.dtype_code(cos_r), cabi.ptr(g_dev), gcap, gs)
         return iota, cos_r, sin_r
 
-    def n_splits_for(self, T: int, S_tot: int) -> int:
+    def attn_choice(self, T: int):
+        """(fused RoPE, work-group rows, split mode) of the attention launch of a T-row step.  Decided once per row class - inside a step
+        where the engine can probe one (_refine_in_step) - so that eager steps, hipGraph steps and lookahead-parallel replicas all launch
+        the same kernels (16-bit partials round alike)."""
+        if self.dtype == torch.float32:
+            return (0, 0, 0)
+        mclass = next((c for c in self.ROW_CLASSES if T <= c), None)
+        if mclass is None or not self.custom_gemm:
+            return (0, 128, 0)
+        if mclass not in self._refined and not self._refining and not torch.cuda.is_current_stream_capturing():
+            for n in self.LAYER_GEMMS:
+                self._tune(n, mclass)
+            self._refine_in_step(mclass)
+        return self.attn_cfg.get(mclass, self.attn_default)
+
+    def n_splits_for(self, T: int, S_tot: int, choice=None) -> int:
         if self.dtype == torch.float32:
             return 1
         forced = int(os.environ.get("LADE_ATTN_SPLITS", "0"))        # experiments only
@@ -396,7 +416,9 @@ class StepEngine:
         # always the split + merge form, and never fewer splits than a 1024-key cache would get: the hipGraph steps are
         # captured with exactly that rule, and an eager step of the same (short) sequence must round the same way
         # (16-bit partials) for the two modes to produce the same token stream
-        return min(ops.choose_splits(self.H, self.H // self.Hkv, T, max(S_tot, 1024), self.n_cu, allow_single=False), self.max_splits)
+        _fuse, wg, mode = choice if choice is not None else self.attn_choice(T)
+        return min(ops.choose_splits(self.H, self.H // self.Hkv, T, max(S_tot, 1024), self.n_cu, allow_single=False,
+                                     block_rows=0 if wg in (0, 128) else wg, mode=mode), self.max_splits)
 
     # ---- GEMM selection ---------------------------------------------------------------------------
     def _tune(self, name: str, M: int):
@@ -592,6 +614,7 @@ class StepEngine:
     # ---- the same decisions, re-taken inside a step ------------------------------------------------------------------------
     STEP_TUNE_LAYERS = 8
     STEP_TUNE_MIN_BYTES = 512 << 20
+    STEP_TUNE_CONTEXT = 2048             # keys of the probe step's cache: a constant, so that the decision does not depend on this engine's S_max
 
     def _refine_in_step(self, mclass: int) -> None:
         """Isolated launches do not rank GEMM configurations the way a step does: back to back on one stream a kernel meets warm caches, no
@@ -601,34 +624,71 @@ class StepEngine:
         re-taken where it counts: hipGraphs of a real forward over the first STEP_TUNE_LAYERS layers (weights >> the Infinity Cache, the
         attention pair, RoPE and both norms in place, the consumers reading the partials), one graph per candidate - the short list x
         ring depths, plus the best candidate of each smaller split count - replayed round-robin; projection after projection
-        (coordinate descent, one pass), a challenger replaces the incumbent only when it wins by > 0.3 %.  The probe step runs on the
-        last T rows of the KV cache (saved and restored) and on no live workspace.  One decision per model shape, row class and process.
-        LADE_TUNE_STEP=0 keeps the isolated pass's table."""
+        (coordinate descent, one pass), a challenger replaces the incumbent only when it wins by > 0.3 %.  Round 5: the ATTENTION launch
+        is the fifth coordinate - (RoPE + KV append fused into it or not) x (work-group rows 128 / 64 / 32) x (split rule), the launch
+        parameters of lade_attn_args - decided the same way on the same graphs.
+        The probe step runs at a FIXED context (STEP_TUNE_CONTEXT keys, or the whole cache of a smaller engine - part of the cache key) on
+        cache rows that are saved and restored, and on no live workspace; workspaces too small for the class's probe rows are grown first.
+        One decision per model shape, row class, probe context and process; never taken during a stream capture (forward() refuses to
+        capture a class whose decision is still open: warm the class up first, or call prepare()).  LADE_TUNE_STEP=0 keeps the isolated table."""
         if mclass in self._refined or self._refining or not self.custom_gemm:
             return
         T = REP_ROWS[mclass]
         esz = self.layers[0]["wo"].element_size() if "wo" in self.layers[0] else self.layers[0]["wo_kt"].element_size()
         layer_bytes = esz * (self.hidden * ((self.H + 2 * self.Hkv) * self.d + self.H * self.d) + 3 * self.hidden * self.inter)
         n_probe = min(self.L, self.STEP_TUNE_LAYERS)
-        if (os.environ.get("LADE_TUNE_STEP", "1") == "0" or layer_bytes * n_probe < self.STEP_TUNE_MIN_BYTES or T > self.max_T
-                or 2 * T > self.S_max or any((n, mclass) not in self.gemm_cfg for n in self.LAYER_GEMMS)):
-            self._refined.add(mclass)          # toy models sit in the Infinity Cache whatever runs: the isolated table stands
+        if not self._step_tunable():
+            self._refined.add(mclass)          # toy models sit in the Infinity Cache whatever runs: the isolated table stands (a property of the MODEL, not of this engine's buffers)
             return
         if torch.cuda.is_current_stream_capturing():
-            return                             # decided at the next eager call (the decoders warm a step up before they capture it)
+            raise cabi.LadeHipError(f"row class {mclass}: the in-step kernel decisions are still open during a stream capture - run the step eagerly once "
+                                    f"(or StepEngine.prepare([rows])) before capturing it")
+        for n in self.LAYER_GEMMS:
+            self._tune(n, mclass)
+        if T > self.max_T:
+            self.grow(self.S_max, T)           # the probe needs T rows of workspace: a decision must not depend on how this engine was sized
+        ctx = min(self.STEP_TUNE_CONTEXT, self.S_max)
         skey = (self.hidden, self.inter, self.H, self.Hkv, self.d, self.L, mclass, str(self.dtype), torch.cuda.get_device_name(self.device),
-                self.n_cu, tuple(self.kt_names), self.gu_layout, tuple(self.gemm_cfg[(n, mclass)] for n in self.LAYER_GEMMS))
+                self.n_cu, tuple(self.kt_names), self.gu_layout, tuple(self.gemm_cfg[(n, mclass)] for n in self.LAYER_GEMMS), ctx, self.attn_default,
+                os.environ.get("LADE_ATTN_TUNE", "1"))
         with _STEP_TUNE_LOCK:
             if skey not in _STEP_TUNE_CACHE:
-                _STEP_TUNE_CACHE[skey] = self._refine_timed(mclass, T, n_probe)
+                _STEP_TUNE_CACHE[skey] = self._refine_timed(mclass, T, n_probe, ctx)
             choice, log = _STEP_TUNE_CACHE[skey]
         for n, c in choice.items():
+            if n == "attn":
+                self.attn_cfg[mclass] = tuple(c)
+                continue
             self.gemm_cfg[(n, mclass)] = c
             ranked = dict((cfg[:5] if cfg else None, t) for t, cfg in reversed(self._ranked.get((n, mclass), [])))
             if (n, mclass) in self.gemm_times:
                 self.gemm_times[(n, mclass)] = (ranked.get(c[:5] if c else None, self.gemm_times[(n, mclass)][0]), self.gemm_times[(n, mclass)][1])
         self.step_tune_log[mclass] = log
         self._refined.add(mclass)
+
+    def _step_tunable(self) -> bool:
+        """whether this MODEL's decisions are re-taken inside a step: its first STEP_TUNE_LAYERS layers must outweigh the Infinity Cache"""
+        if os.environ.get("LADE_TUNE_STEP", "1") == "0" or not self.custom_gemm or not self.layers:
+            return False
+        lw = self.layers[0]
+        esz = (lw["wo"] if "wo" in lw else lw["wo_kt"]).element_size()
+        layer_bytes = esz * (self.hidden * ((self.H + 2 * self.Hkv) * self.d + self.H * self.d) + 3 * self.hidden * self.inter)
+        return layer_bytes * min(self.L, self.STEP_TUNE_LAYERS) >= self.STEP_TUNE_MIN_BYTES and self.S_max >= 512
+
+    def prepare(self, rows: Sequence[int]) -> None:
+        """Takes every kernel decision a step of each of these row counts needs (isolated GEMM pass, the in-step pass, the attention launch
+        parameters) NOW - at construction / before the first request - instead of inside the first live forward of each row class, which
+        would stall that request for seconds (4 projections + the attention launch x up to 18 graph captures)."""
+        if not self.custom_gemm:
+            return
+        with torch.cuda.device(self.device):
+            for T in rows:
+                mclass = next((c for c in self.ROW_CLASSES if T <= c), None)
+                if mclass is None:
+                    continue
+                for n in self.LAYER_GEMMS:
+                    self._tune(n, mclass)
+                self._refine_in_step(mclass)
 
     def _step_candidates(self, name: str, mclass: int):
         ranked = [c for _t, c in self._ranked.get((name, mclass), [])]
@@ -646,63 +706,117 @@ class StepEngine:
                     out.append(cand)
         return out[:18]
 
-    def _refine_timed(self, mclass: int, T: int, n_probe: int):
+    def _attn_candidates(self, mclass: int, T: int, S_tot: int):
+        """(fused, work-group rows, split mode) x what they resolve to at the probe context, one entry per distinct launch"""
+        inc = self.attn_cfg.get(mclass, self.attn_default)
+        if os.environ.get("LADE_ATTN_TUNE", "1") == "0":
+            return [inc]
+        qkv = self.gemm_cfg.get(("wqkv", mclass))
+        fuses = (1, 0) if (qkv is not None and qkv[2] <= 4 and os.environ.get("LADE_FUSE_ROPE", "1") != "0") else (0,)
+        rows = (self.H // self.Hkv) * T
+        shapes = [128, 64] + ([32] if rows <= 64 or self.H != self.Hkv else [])
+        out, seen = [], set()
+        for cand in [inc] + [(f, wg, mode) for f in fuses for wg in shapes for mode in (0, 1, 2)]:
+            if cand[0] and not fuses[0]:
+                continue
+            key = (cand[0], cand[1], self.n_splits_for(T, S_tot, choice=cand))
+            if key not in seen:
+                seen.add(key)
+                out.append(tuple(cand))
+        return out[:18]
+
+    def _refine_timed(self, mclass: int, T: int, n_probe: int, ctx: int):
         dev = self.device
-        P = self.S_max - T
+        P = ctx - T
         gen = torch.Generator(device=dev)
         gen.manual_seed(20240924)
         ids = torch.randint(0, self.V, (T,), device=dev, dtype=torch.int32, generator=gen)
         pos = torch.arange(P, P + T, device=dev, dtype=torch.int32)
         mask = StepMask(T=T, P=P, is_prefill=True)
         sel = torch.zeros(1, dtype=torch.int32, device=dev)
-        n_splits = self.n_splits_for(T, P + T)
         all_layers = self.layers
         kv_saved = [(self._k_views[li][:, P:P + T].clone(), self._vt_views[li][:, :, P:P + T].clone()) for li in range(n_probe)]
         ntk_saved = None if self.ntk_state is None else self.ntk_state.clone()
         saved_ev, self.attn_events = self.attn_events, None
+        saved_attn = self.attn_cfg.get(mclass)
         choice, log = {}, {}
         self._refining = True
         self.layers = all_layers[:n_probe]
+
+        def measure(cands, apply):
+            """one graph per candidate (thread-local capture mode: lookahead-parallel ranks may be threads of this process, and another
+            rank's allocation or synchronisation must not invalidate this capture), replayed round-robin; best time per layer of each"""
+            graphs = []
+            for cand in cands:
+                apply(cand)
+                try:
+                    run = lambda: self.forward(ids, pos, mask, sel, 0, n_splits=self.n_splits_for(T, P + T, choice=self.attn_cfg.get(mclass, self.attn_default)))
+                    run()                                              # eager once: first-launch attributes, argument validation
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        run()
+                except cabi.LadeHipError:
+                    continue
+                graphs.append((cand, g))
+            times = {c: float("inf") for c, _g in graphs}
+            for rnd in range(6):
+                for cand, g in (graphs if rnd % 2 == 0 else graphs[::-1]):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    g.replay()
+                    e1.record()
+                    e1.synchronize()
+                    if rnd > 0:                                        # round 0 warms every graph up
+                        times[cand] = min(times[cand], e0.elapsed_time(e1) / n_probe)
+            del graphs
+            return times
+
         try:
-            run = lambda: self.forward(ids, pos, mask, sel, 0, n_splits=n_splits)
+            self.attn_cfg[mclass] = self.attn_cfg.get(mclass, self.attn_default)
             for name in self.LAYER_GEMMS:
                 inc = self.gemm_cfg[(name, mclass)]
-                graphs = []
-                for cand in self._step_candidates(name, mclass):
+
+                def apply(cand, name=name):
                     self.gemm_cfg[(name, mclass)] = cand
-                    try:
-                        run()                                              # eager once: first-launch attributes, argument validation
-                        torch.cuda.synchronize()
-                        g = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g):
-                            run()
-                    except cabi.LadeHipError:
-                        continue
-                    graphs.append((cand, g))
-                times = {c: float("inf") for c, _g in graphs}
-                for rnd in range(6):
-                    for cand, g in (graphs if rnd % 2 == 0 else graphs[::-1]):
-                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        e0.record()
-                        g.replay()
-                        e1.record()
-                        e1.synchronize()
-                        if rnd > 0:                                        # round 0 warms every graph up
-                            times[cand] = min(times[cand], e0.elapsed_time(e1) / n_probe)
+                times = measure(self._step_candidates(name, mclass), apply)
                 best = min(times, key=times.get)
                 pick = best if times[best] < times.get(inc, float("inf")) * 0.997 else inc
                 self.gemm_cfg[(name, mclass)] = choice[name] = pick
                 log[name] = {"isolated_choice": inc, "in_step_choice": pick, "ms_per_layer_isolated_choice": round(times.get(inc, float("nan")), 5),
-                             "ms_per_layer_in_step_choice": round(times[pick], 5), "candidates": len(graphs)}
+                             "ms_per_layer_in_step_choice": round(times[pick], 5), "candidates": len(times)}
                 if os.environ.get("LADE_TUNE_VERBOSE"):
                     top = " ".join(f"{c}:{t * 1e3:.1f}" for c, t in sorted(times.items(), key=lambda kv: kv[1])[:6])
                     print(f"[tune-step] {name}:{mclass} rows={T} isolated choice {inc} {times.get(inc, float('nan')) * 1e3:.1f} us/layer -> {pick} "
                           f"{times[pick] * 1e3:.1f} | {top}", file=sys.stderr, flush=True)
-                del graphs
+            # the attention launch: fused RoPE + KV append or not, work-group rows, split rule
+            inc = self.attn_cfg[mclass]
+
+            def apply_attn(cand):
+                self.attn_cfg[mclass] = cand
+            times = measure(self._attn_candidates(mclass, T, P + T), apply_attn)
+            if times:
+                best = min(times, key=times.get)
+                pick = best if times[best] < times.get(inc, float("inf")) * 0.997 else inc
+                self.attn_cfg[mclass] = choice["attn"] = tuple(pick)
+                log["attn"] = {"default": inc, "in_step_choice": pick, "ms_per_layer_default": round(times.get(inc, float("nan")), 5),
+                               "ms_per_layer_in_step_choice": round(times[pick], 5), "candidates": len(times), "probe_context": ctx,
+                               "n_splits_at_probe": self.n_splits_for(T, P + T, choice=pick),
+                               "ranked_us_per_layer": [[list(c), round(t * 1e3, 2)] for c, t in sorted(times.items(), key=lambda kv: kv[1])[:8]],
+                               "fields": "(RoPE + KV append fused into the launch, work-group rows, split mode 0 sqrt | 1 fill | 2 half)"}
+                if os.environ.get("LADE_TUNE_VERBOSE"):
+                    top = " ".join(f"{c}:{t * 1e3:.1f}" for c, t in sorted(times.items(), key=lambda kv: kv[1])[:8])
+                    print(f"[tune-step] attn:{mclass} rows={T} default {inc} {times.get(inc, float('nan')) * 1e3:.1f} us/layer -> {pick} {times[pick] * 1e3:.1f} | {top}",
+                          file=sys.stderr, flush=True)
         finally:
             self.layers = all_layers
             self._refining = False
             self.attn_events = saved_ev
+            if "attn" not in choice:
+                if saved_attn is None:
+                    self.attn_cfg.pop(mclass, None)
+                else:
+                    self.attn_cfg[mclass] = saved_attn
             for li, (k, v) in enumerate(kv_saved):
                 self._k_views[li][:, P:P + T].copy_(k)
                 self._vt_views[li][:, :, P:P + T].copy_(v)
@@ -715,20 +829,29 @@ class StepEngine:
     GEMM_NAMES = LAYER_GEMMS + ("lm_head",)
     ROW_CLASSES = (32, 64, 96, 128, 192, 256)
 
+    TUNE_NAMES = GEMM_NAMES + ("attn",)        # rows of the decision table lookahead-parallel ranks exchange (parallel.encode_tune_table)
+
     def tune_all(self) -> dict:
-        """Every (projection, row class) decision of this engine as a plain dict (lookahead parallelism: rank 0 tunes,
-        the other ranks adopt its table through `adopt_gemm_cfg`, so that all replicas round alike)."""
+        """Every (projection, row class) decision of this engine - and the attention launch parameters per row class (`attn:<class>` =
+        (fused RoPE, work-group rows, split mode, 0, 0, 0)) - as a plain dict (lookahead parallelism: rank 0 tunes, the other ranks adopt
+        its table through `adopt_gemm_cfg`, so that all replicas round alike)."""
         if not self.custom_gemm:
             return {}
         for m in self.ROW_CLASSES:
             for n in self.GEMM_NAMES:
                 self._tune(n, m)
             self._refine_in_step(m)
-        return {f"{n}:{m}": self.gemm_cfg[(n, m)] for n in self.GEMM_NAMES for m in self.ROW_CLASSES}
+        out = {f"{n}:{m}": self.gemm_cfg[(n, m)] for n in self.GEMM_NAMES for m in self.ROW_CLASSES}
+        out.update({f"attn:{m}": tuple(self.attn_cfg.get(m, self.attn_default)) + (0, 0, 0) for m in self.ROW_CLASSES})
+        return out
 
     def adopt_gemm_cfg(self, table: dict) -> None:
         for k, v in table.items():
             n, m = k.split(":")
+            if n == "attn":
+                if v is not None:
+                    self.attn_cfg[int(m)] = tuple(int(x) for x in v[:3])
+                continue
             self.gemm_cfg[(n, int(m))] = None if v is None else (tuple(v) + (0,))[:6]       # (a 5-tuple of an older table: default ring)
             self._refined.add(int(m))                # an adopted decision is final: every replica must run the kernels rank 0 chose
 
@@ -748,18 +871,25 @@ class StepEngine:
         H, Hkv, d = self.H, self.Hkv, self.d
         x, h, r = self.ws_x[:T], self.ws_h[:T], self.ws_r[:T]
         qkv, o, gu, a = self.ws_qkv[:T], self.ws_o[:T], self.ws_gu[:T], self.ws_a[:T]
-        if n_splits is None:
-            n_splits = self.n_splits_for(T, P + T)
         fused = self.custom_gemm and T <= self.ROW_CLASSES[-1]
+        if fused and not self._refining:
+            mclass = next(c for c in self.ROW_CLASSES if T <= c)
+            if mclass not in self._refined:          # once per row class: the decisions re-taken INSIDE a step - BEFORE this call touches a workspace
+                for n in self.LAYER_GEMMS:
+                    self._tune(n, mclass)
+                self._refine_in_step(mclass)         # (raises during a stream capture: a graph must never bake a table that later eager steps do not use)
+                x, h, r = self.ws_x[:T], self.ws_h[:T], self.ws_r[:T]            # (the probe may have grown the workspaces)
+                qkv, o, gu, a = self.ws_qkv[:T], self.ws_o[:T], self.ws_gu[:T], self.ws_a[:T]
         cfg_qkv = self._tune("wqkv", T) if fused else None
         cfg_o = self._tune("wo", T) if fused else None
         cfg_gu = self._tune("wgu", T) if fused else None
         cfg_d = self._tune("wd", T) if fused else None
-        if fused and not self._refining:
-            mclass = next(c for c in self.ROW_CLASSES if T <= c)
-            if mclass not in self._refined:          # once per row class: the four decisions re-taken INSIDE a step - BEFORE this call touches a workspace
-                self._refine_in_step(mclass)
-                cfg_qkv, cfg_o, cfg_gu, cfg_d = (self.gemm_cfg[(n, mclass)] for n in self.LAYER_GEMMS)
+        # the attention launch of this row class: RoPE + KV append inside it (from the qkv GEMM's partials) or as a launch of their own,
+        # the work-group shape, the split rule
+        acfg = (self.attn_cfg.get(next(c for c in self.ROW_CLASSES if T <= c), self.attn_default) if fused else (0, 0, 0))
+        if n_splits is None:
+            n_splits = self.n_splits_for(T, P + T, choice=acfg if fused else None)
+        fuse_rope = bool(acfg[0]) and cfg_qkv is not None and cfg_qkv[2] <= 4 and not self.skip_attn
         fuse_embed = os.environ.get("LADE_FUSE_TAIL", "1") != "0"      # embedding lookup inside the first layer's input norm (one launch less)
         if not (fuse_embed and self.layers):
             ops.gather_rows(self.embed, ids, out=x, rows=T)
@@ -778,7 +908,8 @@ class StepEngine:
             if cfg_qkv:
                 ops.gemm_parts(h, self._w(lw, "wqkv"), part, cfg_qkv[2], cfg_qkv[1], cfg_qkv[0], cfg_qkv[3], cfg_qkv[4], cfg_qkv[5])
                 qb = self.ws_q[:T]
-                ops.rope_kv_append_parts(part, cfg_qkv[2], qb, rpos, rcos, rsin, self.k_cache(li), self.vt_cache(li), T, P, H=H, Hkv=Hkv, d=d, dyn_P=dyn_P)
+                if not fuse_rope and self.skip_attn != "all":
+                    ops.rope_kv_append_parts(part, cfg_qkv[2], qb, rpos, rcos, rsin, self.k_cache(li), self.vt_cache(li), T, P, H=H, Hkv=Hkv, d=d, dyn_P=dyn_P)
                 q_in = qb
             else:
                 torch.matmul(h, self._row(lw, "wqkv").t(), out=qkv)
@@ -793,9 +924,13 @@ class StepEngine:
                     self.attn_events_empty.append((c0, c1))
                 e0 = torch.cuda.Event(enable_timing=True)
                 e0.record()
-            if not self.skip_attn:
+            if fuse_rope:
+                # q and the new K / V rows straight from the qkv GEMM's partials: no RoPE launch (same bits as the two-launch form)
+                ops.attn_fwd(None, self.k_cache(li), self.vt_cache(li), mask, H=H, Hkv=Hkv, d=d, out=o, n_splits=n_splits, part_o=self.part_o,
+                             part_ml=self.part_ml, dyn_P=dyn_P, wg_rows=acfg[1], qkv_parts=part, n_parts=cfg_qkv[2], positions=rpos, cos=rcos, sin=rsin)
+            elif not self.skip_attn:
                 ops.attn_fwd(q_in, self.k_cache(li), self.vt_cache(li), mask, H=H, Hkv=Hkv, d=d, out=o, n_splits=n_splits,
-                             part_o=self.part_o, part_ml=self.part_ml, dyn_P=dyn_P)
+                             part_o=self.part_o, part_ml=self.part_ml, dyn_P=dyn_P, wg_rows=acfg[1])
             if ev is not None:
                 e1 = torch.cuda.Event(enable_timing=True)
                 e1.record()

@@ -52,60 +52,113 @@ def attn_block_rows(n_rep: int, T: int) -> int:
     return 32 if rows <= 32 else (64 if rows <= 64 else 128)
 
 
-def choose_splits(H: int, n_rep: int, T: int, S_tot: int, n_cu: int = 256, allow_single: bool = True) -> int:
+def choose_splits(H: int, n_rep: int, T: int, S_tot: int, n_cu: int = 256, allow_single: bool = True, block_rows: int = 0, mode: int = 0) -> int:
     """KV splits of the lookahead attention.  One CU ingests only ~55-68 GB/s from HBM (tools/hbm_probe), so the
-    grid (row blocks x KV heads x splits) should cover every CU once.  Split s takes the 64-key tiles s, s+n, s+2n, ...
-    (interleaved: the splits differ by at most one tile), so any count up to the tile count is balanced."""
-    br = attn_block_rows(n_rep, T)
+    grid (row blocks x KV heads x splits) should cover the CUs; a split is a contiguous range of 64-key tiles.
+    block_rows: the work-group shape the launch will use (0: the 128-row default for more than 64 rows, else the smallest that holds them).
+    mode 0: the sqrt rule below; 1: fill the CUs regardless of the merge cost; 2: half the sqrt rule's count (GQA heads whose partial
+    round trip dominates) - the engine's in-step autotune picks (shape, mode) per row class (StepEngine._refine_in_step)."""
+    br = block_rows or attn_block_rows(n_rep, T)
     blocks = (H // n_rep) * ((n_rep * T + br - 1) // br)
     tiles = max(1, (S_tot + 63) // 64)
     if tiles <= 5 and allow_single:               # <= 320 keys: one work-group per head beats a second (merge) launch
         return 1
     forced = int(os.environ.get("LADE_ATTN_SPLIT_RULE", "0"))     # experiments: 1 = fill the CUs regardless of the merge cost
     fill = max(1, n_cu // max(blocks, 1))
-    if forced == 1:
-        return max(1, min(fill, tiles, 32))
-    # streaming time per work-group falls as tiles/splits, the merge (and the partial round trip) grows with splits: the measured
-    # optimum follows sqrt(tiles) - 5 splits at 18 tiles, 6 at 34, 8 at 65 (round 2, isolated pair at 34 tiles: 16.8 us with 6
-    # splits, 17.1 us with 8)
-    want = max(1, min(fill, math.isqrt(max(tiles - 1, 0)) + 1, tiles, 32))
+    if forced == 1 or mode == 1:
+        want = max(1, min(fill, tiles, 32))
+    else:
+        # streaming time per work-group falls as tiles/splits, the merge (and the partial round trip) grows with splits: the measured
+        # optimum follows sqrt(tiles) - 5 splits at 18 tiles, 6 at 34, 8 at 65 (round 2, isolated pair at 34 tiles: 16.8 us with 6
+        # splits, 17.1 us with 8)
+        want = max(1, min(fill, math.isqrt(max(tiles - 1, 0)) + 1, tiles, 32))
+        if mode == 2:
+            want = max(1 if allow_single else 2, (want + 1) // 2)
     tps = (tiles + want - 1) // want              # tiles per split
     return (tiles + tps - 1) // tps               # drop the splits that would be empty
 
 
-def attn_fwd(q: torch.Tensor, k_cache: torch.Tensor, vt_cache: torch.Tensor, mask: StepMask, *, H: int, Hkv: int, d: int,
+_HALVES_OK: dict = {}
+
+
+def _check_rope_halves(cos: torch.Tensor, sin: torch.Tensor) -> None:
+    """the fused RoPE loads ONE 16-byte vector per table for columns i.. and i + d/2..: valid for rotary tables built as cat(freqs, freqs)
+    (lade/models/modeling_llama.py:252), which is checked once per table"""
+    key = (cos.data_ptr(), sin.data_ptr(), tuple(cos.shape), cos._version, sin._version)
+    if key not in _HALVES_OK:
+        if torch.cuda.is_current_stream_capturing():
+            return                                # (checked at the eager warm-up that precedes every capture)
+        h = cos.shape[1] // 2
+        if not (torch.equal(cos[:, :h], cos[:, h:]) and torch.equal(sin[:, :h], sin[:, h:])):
+            raise cabi.LadeHipError("fused RoPE needs cos / sin tables whose two halves are equal (emb = cat(freqs, freqs))")
+        if len(_HALVES_OK) > 256:
+            _HALVES_OK.clear()
+        _HALVES_OK[key] = True
+
+
+def attn_fwd(q: Optional[torch.Tensor], k_cache: torch.Tensor, vt_cache: torch.Tensor, mask: StepMask, *, H: int, Hkv: int, d: int,
              out: Optional[torch.Tensor] = None, n_splits: Optional[int] = None, scale: Optional[float] = None,
              q_row_stride: Optional[int] = None, part_o: Optional[torch.Tensor] = None, part_ml: Optional[torch.Tensor] = None,
-             dyn_P: Optional[torch.Tensor] = None) -> torch.Tensor:
+             dyn_P: Optional[torch.Tensor] = None, wg_rows: int = 0, qkv_parts: Optional[torch.Tensor] = None, n_parts: int = 0,
+             positions: Optional[torch.Tensor] = None, cos: Optional[torch.Tensor] = None, sin: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Lookahead attention for one step.  q: [T, >=H*d] rows (token stride q_row_stride elements, default
-    q.stride(0)); k_cache [Hkv, S_max, d]; vt_cache [Hkv, d, S_max]; returns out [T, H*d]."""
-    for n, t in (("q", q), ("k_cache", k_cache), ("vt_cache", vt_cache)):
+    q.stride(0)); k_cache [Hkv, S_max, d]; vt_cache [Hkv, d, S_max]; returns out [T, H*d].
+    wg_rows: work-group shape (0 = default, 32 | 64 | 128 query rows per work-group).
+    Fused RoPE + KV append (qkv_parts given): q is not read; q and the new K / V rows P..P+T come from the qkv projection's n_parts (1..4)
+    fp32 split-K partials `qkv_parts` ([>= n_parts][T][(H + 2 Hkv) d] with stride qkv_parts.stride(0), or flat with stride T (H + 2 Hkv) d), rotated with the
+    cos / sin rows positions[t] (positions None: row t) - the rows are written to the caches and the result equals
+    rope_kv_append_parts + attn_fwd bit for bit."""
+    for n, t in (("k_cache", k_cache), ("vt_cache", vt_cache)):
         _dev(t, n)
     T = mask.T
     S_max = k_cache.shape[1]
     assert k_cache.shape == (Hkv, S_max, d) and vt_cache.shape == (Hkv, d, S_max), (k_cache.shape, vt_cache.shape)
-    assert k_cache.is_contiguous() and vt_cache.is_contiguous() and q.stride(-1) == 1
+    assert k_cache.is_contiguous() and vt_cache.is_contiguous()
+    dt = k_cache.dtype
+    fused = qkv_parts is not None
+    if fused:
+        assert n_parts >= 1 and cos is not None and sin is not None and qkv_parts.dtype == torch.float32 and dt != torch.float32
+        assert cos.dtype == dt and cos.shape[1] == d and cos.is_contiguous() and sin.is_contiguous() and sin.shape == cos.shape
+        assert positions is None or (positions.dtype == torch.int32 and positions.numel() >= T)
+        row_w = (H + 2 * Hkv) * d
+        part_stride = qkv_parts.stride(0) if qkv_parts.dim() == 3 else T * row_w
+        assert qkv_parts.numel() >= (n_parts - 1) * part_stride + T * row_w
+        _check_rope_halves(cos, sin)
+    else:
+        _dev(q, "q")
+        assert q.stride(-1) == 1 and q.dtype == dt
+    dev = k_cache.device
     if out is None:
-        out = torch.empty(T, H * d, dtype=q.dtype, device=q.device)
+        out = torch.empty(T, H * d, dtype=dt, device=dev)
     if n_splits is None:
-        n_splits = 1 if q.dtype == torch.float32 else choose_splits(H, H // Hkv, T, mask.P + T)
-    if q.dtype == torch.float32:
+        n_splits = 1 if dt == torch.float32 else choose_splits(H, H // Hkv, T, mask.P + T)
+    if dt == torch.float32:
         n_splits = 1
     if n_splits > 1:
         if part_o is None:
-            part_o = torch.empty(n_splits, T, H, d, dtype=q.dtype, device=q.device)
+            part_o = torch.empty(n_splits, T, H, d, dtype=dt, device=dev)
         if part_ml is None:
-            part_ml = torch.empty(n_splits, H, T, 2, dtype=torch.float32, device=q.device)
+            part_ml = torch.empty(n_splits, H, T, 2, dtype=torch.float32, device=dev)
     a = AttnArgs(ptr(q), ptr(k_cache), ptr(vt_cache), ptr(out), ptr(part_o), ptr(part_ml), ptr(dyn_P),
-                 q_row_stride if q_row_stride is not None else q.stride(0), out.stride(0), H, Hkv, d, S_max,
-                 dtype_code(q), n_splits, scale if scale is not None else 1.0 / math.sqrt(d), mask.c_struct())
+                 (q_row_stride if q_row_stride is not None else q.stride(0)) if q is not None else 0, out.stride(0), H, Hkv, d, S_max,
+                 DTYPE_CODE_OF(dt), n_splits, scale if scale is not None else 1.0 / math.sqrt(d), mask.c_struct(), int(wg_rows))
+    if fused:
+        a.n_parts, a.qkv_parts, a.part_stride = int(n_parts), ptr(qkv_parts), int(part_stride)
+        a.positions, a.cos_tab, a.sin_tab, a.max_pos = ptr(positions), ptr(cos), ptr(sin), int(cos.shape[0])
     call("lade_attn_fwd", C.byref(a))
     if n_splits > 1:
         call("lade_attn_combine", C.byref(a))
     return out
 
 
-def time_attn(q, k_cache, vt_cache, mask: StepMask, *, H, Hkv, d, n_splits: int, reps: int = 20, debug_timeline: bool = False):
+def DTYPE_CODE_OF(dt: torch.dtype) -> int:
+    try:
+        return cabi.DTYPE_CODE[dt]
+    except KeyError:
+        raise cabi.LadeHipError(f"unsupported dtype {dt}")
+
+
+def time_attn(q, k_cache, vt_cache, mask: StepMask, *, H, Hkv, d, n_splits: int, reps: int = 20, debug_timeline: bool = False, wg_rows: int = 0):
     """Mean duration in microseconds of one attention launch (+combine), measured with hipEvents on the launch stream
     inside the library.  k_cache / vt_cache may be LISTS of caches: they are used round-robin, one per repetition, so
     that with enough of them (total > the 256 MB Infinity Cache) every launch streams its K/V from HBM like the
@@ -121,7 +174,7 @@ def time_attn(q, k_cache, vt_cache, mask: StepMask, *, H, Hkv, d, n_splits: int,
     arr = (AttnArgs * len(ks))()
     for i, (k, v) in enumerate(zip(ks, vs)):
         arr[i] = AttnArgs(ptr(q), ptr(k), ptr(v), ptr(out), ptr(part_o), ptr(part_ml), None, q.stride(0), out.stride(0),
-                          H, Hkv, d, S_max, dtype_code(q), n_splits, 1.0 / math.sqrt(d), mask.c_struct())
+                          H, Hkv, d, S_max, dtype_code(q), n_splits, 1.0 / math.sqrt(d), mask.c_struct(), int(wg_rows))
     us = C.c_float(0.0)
     if len(ks) == 1:
         call("lade_time_attn", C.byref(arr[0]), reps, C.byref(us))

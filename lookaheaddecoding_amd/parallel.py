@@ -336,12 +336,12 @@ class HipLPBackend:
         if getattr(e, "_lp_gemm_synced", False) or not e.custom_gemm or lp.R == 1:
             return
         if self.comm is not None:
-            words = encode_tune_table(e.tune_all() if lp.rank == 0 else {}, e.GEMM_NAMES, e.ROW_CLASSES)
+            words = encode_tune_table(e.tune_all() if lp.rank == 0 else {}, e.TUNE_NAMES, e.ROW_CLASSES)
             mine = torch.tensor(words, dtype=torch.int32, device=self.device)
             allw = torch.zeros(lp.R * mine.numel(), dtype=torch.int32, device=self.device)
             self.comm.all_gather(allw, mine)
             if lp.rank != 0:
-                e.adopt_gemm_cfg(decode_tune_table(allw[:mine.numel()].tolist(), e.GEMM_NAMES, e.ROW_CLASSES))
+                e.adopt_gemm_cfg(decode_tune_table(allw[:mine.numel()].tolist(), e.TUNE_NAMES, e.ROW_CLASSES))
         elif dist.is_available() and dist.is_initialized():
             box = [e.tune_all() if lp.rank == 0 else None]
             dist.broadcast_object_list(box, src=0, group=lp.group)

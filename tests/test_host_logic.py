@@ -211,3 +211,38 @@ def test_rendezvous_ports_are_picked_below_the_ephemeral_range():
         s = socket.socket()
         s.bind(("127.0.0.1", p))          # really free
         s.close()
+
+
+def test_flash_lookahead_tuple_maps_onto_the_closed_form_mask():
+    """`flash_attn_func(..., lookahead=[window, level, n_guess, kv_cache, fill_offset, guess_offset, 0])` (lade/models/modeling_llama.py:705-713,
+    tuple built at :1184-1187): the adapter's mapping of the tuple equals the mask description the engine derives from the step's level
+    sizes, for every step of the reference's own greedy runs, and the reference's seqlen identity (:706-709) is enforced."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from lookaheaddecoding_amd.flash_attn_lade import lookahead_tuple, mask_from_lookahead
+    from lookaheaddecoding_amd.ops import StepMask
+    n = 0
+    for name in ("e2e_greedy.json", "e2e_greedy_wide.json"):
+        with open(os.path.join(GOLDEN, name)) as f:
+            runs = json.load(f)["runs"]
+        for run in runs:
+            gs = run["N"] - 1
+            for tr in run["trace"]:
+                ls, lg, ni, P = tr["level_sizes"], tr["lguess"], tr["n_input"], tr["P"]
+                if len(ls) > 1 and any(x != ls[1] for x in ls[1:]):
+                    continue                      # ragged levels: the reference cannot build its flash row order (:1483)
+                T = ni + sum(ls) + lg
+                tup = lookahead_tuple(ni, ls, lg // gs, P)
+                assert tup == [ls[-1], len(ls) + 1, lg // gs, P, ni - 1 + 1 + ls[0] - ls[-1], ni - 1, 0]
+                m = mask_from_lookahead(tup, T, P + T)
+                want = StepMask.from_levels(ni, ls, lg, gs, P, layout=1)
+                if lg == 0:
+                    want.gs = m.gs                # without candidates `level - 1` follows the fill level, and gs is not read
+                assert m == want, (tup, m, want)
+                with pytest.raises(AssertionError, match="Setups"):
+                    mask_from_lookahead(tup, T + 1, P + T + 1)
+                n += 1
+    assert n > 300
+    assert mask_from_lookahead([0, 0, 0, 40, 0, 0, 0], 9, 49) == StepMask(T=9, P=40, is_prefill=True)
+    assert mask_from_lookahead(None, 9, 49) == StepMask(T=9, P=40, is_prefill=True)
