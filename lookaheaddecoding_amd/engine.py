@@ -171,9 +171,11 @@ class StepEngine:
         self._refined = set()               # row classes whose decisions were re-taken inside the step (_refine_in_step)
         self._refining = False
         # attention launch parameters per row class: (RoPE + KV append fused into the launch, work-group rows, split mode of ops.choose_splits);
-        # the default until (unless) the in-step pass decides: LADE_FUSE_ROPE (default 1), the 128-row shape, the sqrt split rule
+        # the default until (unless) the in-step pass decides: RoPE + append as a launch of their own (the fused form measured +3.7 us per
+        # layer at the 7B step - every split re-reads the q rows as fp32 partials; LADE_FUSE_ROPE=1 makes it the default, the
+        # in-step pass always tries both), the 128-row shape, the sqrt split rule
         self.attn_cfg = {}
-        self.attn_default = (1 if os.environ.get("LADE_FUSE_ROPE", "1") != "0" else 0, 128, 0)
+        self.attn_default = (1 if os.environ.get("LADE_FUSE_ROPE", "0") == "1" else 0, 128, 0)
         self.step_tune_log = {}             # row class -> what the in-step pass measured (bench.py prints it)
         self._alloc_workspaces(max_T)
         try:
@@ -712,7 +714,7 @@ class StepEngine:
         if os.environ.get("LADE_ATTN_TUNE", "1") == "0":
             return [inc]
         qkv = self.gemm_cfg.get(("wqkv", mclass))
-        fuses = (1, 0) if (qkv is not None and qkv[2] <= 4 and os.environ.get("LADE_FUSE_ROPE", "1") != "0") else (0,)
+        fuses = (1, 0) if (qkv is not None and qkv[2] <= 4 and os.environ.get("LADE_FUSE_ROPE", "") != "off") else (0,)
         rows = (self.H // self.Hkv) * T
         shapes = [128, 64] + ([32] if rows <= 64 or self.H != self.Hkv else [])
         out, seen = [], set()
