@@ -101,19 +101,19 @@ def attn_useful_flops(cfg, T, P, W, N, g):
     return 4 * cfg["head_dim"] * cfg["heads"] * (T * P + vis)
 
 
-def pmc_traffic(cfg, T, P, n_splits):
+def pmc_traffic(cfg, T, P, n_splits, wg_rows=128):
     """HBM bytes per launch pair from the rocprofv3 PMC passes committed under profiles/ (bench.py cannot collect counters
     itself): FETCH_SIZE (x2 on gfx950 for wide coalesced reads, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KiB -> bytes,
     attention + combine kernels.  Only reported when a profiled launch has THIS run's shape - heads, KV heads, head size, T, split
     count, and the cache length within 128 keys; returns (bytes, source file)."""
     H, Hkv, d = cfg["heads"], cfg["kv_heads"], cfg["head_dim"]
-    for name in ("r4_attn_pmc.json", "r3_attn_pmc.json", "r2_attn_pmc.json"):
+    for name in ("r5_attn_pmc.json", "r4_attn_pmc.json", "r3_attn_pmc.json", "r2_attn_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as f:
                 for e in json.load(f)["entries"]:
                     shape = (e.get("H", 32), e.get("Hkv", 32), e.get("d", 128))       # round-2 entries: the 7B heads
-                    if shape == (H, Hkv, d) and e["T"] == T and abs(e["P"] - P) <= 128 and e["n_splits"] == n_splits:      # 128 keys = 2 MB of 36: within the counters' spread
+                    if shape == (H, Hkv, d) and e["T"] == T and abs(e["P"] - P) <= 128 and e["n_splits"] == n_splits and e.get("wg_rows", 128) == (wg_rows or 128):      # 128 keys = 2 MB of 36: within the counters' spread
                         return e["traffic_bytes"], f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/attn_bench.py at this shape; not collected by this run)"
         except Exception:
             pass
@@ -806,7 +806,7 @@ def worker(args):
         alg = attn_algorithmic_bytes(cfg, T_k, P_end)
         flops = attn_useful_flops(cfg, T_k, P_end, W, N, g_mid) if not use_lp else 4 * cfg["head_dim"] * cfg["heads"] * T_k * P_end
         achieved = alg / (us * 1e-6) / 1e9
-        traffic, traffic_source = pmc_traffic(cfg, T_k, P_end, ns)
+        traffic, traffic_source = pmc_traffic(cfg, T_k, P_end, ns, acfg_k[1])
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
                     "traffic": traffic, "traffic_source": traffic_source,
                     "kernel": f"lade::attn_fwd_kernel<{args.dtype},{cfg['head_dim']}> (+combine, n_splits={ns})",

@@ -78,6 +78,15 @@ __device__ __forceinline__ uint32_t pack2<F16>(float lo, float hi) {
     return (uint32_t)from_f32<F16>(lo) | ((uint32_t)from_f32<F16>(hi) << 16);
 }
 
+// torch.argmax's order, one definition for lade_argmax_rows, lade_argmax_pairs and the lm_head GEMM's argmax epilogue: a NaN is the maximum
+// (the first NaN of a row wins), among equal values the lowest index wins; bi == 0x7fffffff = nothing seen yet
+__device__ __forceinline__ bool argmax_better(float v, int i, float best, int bi) {
+    const bool vn = v != v, bn = best != best;
+    if (bi == 0x7fffffff) return true;
+    if (vn) return !bn || i < bi;
+    return !bn && (v > best || (v == best && i < bi));
+}
+
 // storage-type helpers: 16-bit types round after every elementwise op exactly like torch does
 // (fp32 math, one rounding per op); fp32 uses separately rounded mul / add (no contraction).
 template <typename T> struct Elem;

@@ -77,7 +77,11 @@ static int gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, b
     LADE_REQUIRE(mb >= 1 && mb <= 8 && mt >= 1 && mt <= 4 && mb % mt == 0, LADE_E_ARG, "lade_gemm_skinny: mb=%d mt=%d", mb, mt);
     // 192 / 256-row work-groups: the activation tile leaves room for <= 128 weight rows per stage of a 3-stage ring; the one wider
     // shape is the double-buffered 256 x 256 tile (mb = 8, bn = 256, nt = 2 | 4)
-    if (mb > 4 && bn > 128 && !(mb == 8 && bn == 256 && (nt == 2 || nt == 4))) bn = 128;
+    if (mb > 4 && bn > 128 && !(mb == 8 && bn == 256 && (nt == 2 || nt == 4))) {
+        // (the argmax epilogue's pair buffer is indexed by the CALLER's ceil(N / bn): a silently narrower block would shift every row's pairs)
+        LADE_REQUIRE(epilogue != 2, LADE_E_ARG, "lade_gemm_skinny: epilogue 2 with mb=%d needs bn <= 128 (got %d): the pair buffer's stride is ceil(N / bn)", mb, bn);
+        bn = 128;
+    }
     const int mw = mb / mt;
     const int tiles = bn <= 32 ? 1 : (bn <= 64 ? 2 : (bn <= 96 ? 3 : (bn <= 128 ? 4 : (bn <= 192 ? 6 : (bn <= 224 ? 7 : 8)))));      // 32-row weight tiles per work-group
     if (nt == 0) {                                     // default: as many n-groups as waves allow

@@ -245,11 +245,11 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
                     for (int e = 0; e < 4; ++e) {
                         const int n = n0 + (ng * NT + j) * 32 + 8 * g4 + 4 * hi + e;
                         const float v = g_rnd<T>(acc[a][j][4 * g4 + e]);
-                        if (n < g.N && (v > best || bi == 0x7fffffff)) { best = v; bi = n; }
+                        if (n < g.N && argmax_better(v, n, best, bi)) { best = v; bi = n; }
                     }
             const float ob = __shfl_xor(best, 32);
             const int oi = __shfl_xor(bi, 32);
-            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            if (oi != 0x7fffffff && argmax_better(ob, oi, best, bi)) { best = ob; bi = oi; }
             if (hi == 0) {
                 sv[ng * BM + (mw * MT + a) * 32 + ql] = best;
                 si[ng * BM + (mw * MT + a) * 32 + ql] = bi;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
             for (int q = 1; q < NG; ++q) {
                 const float ob = sv[q * BM + tid];
                 const int oi = si[q * BM + tid];
-                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+                if (oi != 0x7fffffff && argmax_better(ob, oi, best, bi)) { best = ob; bi = oi; }
             }
             float* dst = g.Cpart + ((size_t)(m0 + tid) * gridDim.x + blockIdx.x) * 2;
             *reinterpret_cast<float2*>(dst) = float2{best, __int_as_float(bi)};

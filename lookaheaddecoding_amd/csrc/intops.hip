@@ -285,7 +285,7 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(const void* logits, i
     float best = -INFINITY;
     int bi = 0x7fffffff;
     auto upd = [&](float v, int i) {
-        if (v > best || (v == best && i < bi) || bi == 0x7fffffff) { best = v; bi = i; }
+        if (argmax_better(v, i, best, bi)) { best = v; bi = i; }
     };
     constexpr bool is16 = !__is_same(T, F32);
     constexpr int VEC = is16 ? 8 : 4;
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(const void* logits, i
     for (int o = 32; o > 0; o >>= 1) {
         const float ob = __shfl_xor(best, o);
         const int oi = __shfl_xor(bi, o);
-        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        if (oi != 0x7fffffff && argmax_better(ob, oi, best, bi)) { best = ob; bi = oi; }
     }
     __shared__ float sb[16];
     __shared__ int si[16];
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(const void* logits, i
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 16; ++w)
-            if (sb[w] > best || (sb[w] == best && si[w] < bi)) { best = sb[w]; bi = si[w]; }
+            if (si[w] != 0x7fffffff && argmax_better(sb[w], si[w], best, bi)) { best = sb[w]; bi = si[w]; }
         out[row] = bi;
     }
 }
@@ -355,13 +355,13 @@ __global__ __launch_bounds__(64) void argmax_pairs_kernel(const float2* pairs, i
         for (int k = 0; k < R; ++k)
             if (b0 + k * 64 + lane < nb) {
                 const int oi = __float_as_int(v[k].y);
-                if (v[k].x > best || (v[k].x == best && oi < bi) || bi == 0x7fffffff) { best = v[k].x; bi = oi; }
+                if (argmax_better(v[k].x, oi, best, bi)) { best = v[k].x; bi = oi; }
             }
     }
     for (int o = 32; o > 0; o >>= 1) {
         const float ob = __shfl_xor(best, o);
         const int oi = __shfl_xor(bi, o);
-        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        if (oi != 0x7fffffff && argmax_better(ob, oi, best, bi)) { best = ob; bi = oi; }
     }
     if (lane == 0) out[row] = bi;
 }

@@ -370,9 +370,16 @@ class StepEngine:
         return self._vt_views[layer]
 
     def reset(self) -> None:
+        """A new sequence on this model.  The dynamic-NTK "longest length seen" is NOT reset: in the reference it lives on the rotary module
+        (`max_seq_len_cached` + the rebuilt inv_freq, lade/models/modeling_llama.py:243-246, :299-316) and survives from one generate() call to the
+        next - a second, shorter generation rotates with the largest base the first one reached (tests/golden/e2e_dynamic_ntk_again.json:
+        reference runs whose second call differs from a fresh model's).  `reset_rope_state()` is the fresh model."""
         self.kv.zero_()
+
+    def reset_rope_state(self) -> None:
+        """dynamic NTK only: forget the longest length seen (= a freshly constructed reference model: max_seq_len_cached = max_position_embeddings)"""
         if self._ntk is not None:
-            self._ntk["state"].fill_(self._ntk["mp"])          # a new sequence: max_seq_len_cached = max_position_embeddings again
+            self._ntk["state"].fill_(self._ntk["mp"])
 
     @property
     def ntk_state(self) -> Optional[torch.Tensor]:

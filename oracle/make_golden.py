@@ -381,6 +381,33 @@ def gen_e2e_dynamic_ntk():
               "longest step", max(st["step_len"] for st in rec.steps))
     dump("e2e_dynamic_ntk.json", {"runs": runs})
 
+def gen_e2e_dynamic_ntk_again():
+    """Two CONSECUTIVE generate() calls on ONE reference model under rope_scaling = dynamic: `max_seq_len_cached` and the rebuilt `inv_freq`
+    live on the rotary module (modeling_llama.py:243-246, :299-316) and are never reset, so the second call starts from the LARGEST base the
+    first one reached - its early steps rotate with other tables than a fresh model's would (round-4 advice: the port reset that state per
+    sequence).  Call 2 is shorter than call 1, so it never rebuilds at all.  Also recorded: what a FRESH model yields for call 2."""
+    runs = []
+    # (weights drawn wider than the other fixtures' - std 0.25 / 0.3 - and a larger factor: the tiny models of MODELS are nearly insensitive to
+    # the rotation base, and the point of this fixture is that the second call's tokens DIFFER from a fresh model's)
+    for (mname, wseed, std, W, N, G, seed, mp, factor, p1, new1, p2, new2) in [("tiny-d64", 11, 0.25, 5, 4, 5, 1, 16, 8.0, "rep", 72, "rep2", 24),
+                                                                              ("tiny-d16", 12, 0.3, 4, 3, 4, 2, 16, 8.0, "rnd", 64, "rep", 20)]:
+        cfg = make_config(mname, max_pos=mp, rope_scaling={"type": "dynamic", "factor": factor})
+        w = random_weights_numpy(cfg, seed=wseed, std=std)
+        model = build_ref_model(cfg, w)
+        calls = []
+        for (pname, new) in ((p1, new1), (p2, new2)):
+            prompt = [t % cfg["vocab"] for t in PROMPTS[pname]]
+            toks, steps, gen, rec = run_ref_greedy(model, prompt, W, N, G, len(prompt) + new, seed, 0, None, ())
+            calls.append({"prompt": prompt, "max_length": len(prompt) + new, "tokens": toks, "steps": steps, "generated": gen,
+                          "longest_step": max(st["step_len"] for st in rec.steps)})
+        fresh = build_ref_model(cfg, w)
+        prompt2 = calls[1]["prompt"]
+        toks_f, steps_f, _g, _r = run_ref_greedy(fresh, prompt2, W, N, G, calls[1]["max_length"], seed, 0, None, ())
+        runs.append({"model": mname, "model_seed": wseed, "std": std, "W": W, "N": N, "G": G, "seed": seed, "max_pos": mp,
+                     "rope_scaling": cfg["rope_scaling"], "calls": calls, "second_call_on_a_fresh_model": {"tokens": toks_f, "steps": steps_f}})
+        print("dynamic-ntk again", mname, [(c["steps"], c["generated"], c["longest_step"]) for c in calls], "fresh-model call 2 differs:", toks_f != calls[1]["tokens"])
+    dump("e2e_dynamic_ntk_again.json", {"runs": runs})
+
 # ------------------------------------------------------------------ sampling
 
 
@@ -550,3 +577,5 @@ if __name__ == "__main__":
         gen_e2e_sample_eos()
     if "dynamic_ntk" in what:          # round 4: a separate fixture, the others stay byte-identical
         gen_e2e_dynamic_ntk()
+    if "dynamic_ntk_again" in what:    # round 5: two consecutive calls on one model
+        gen_e2e_dynamic_ntk_again()

@@ -280,7 +280,8 @@ def test_dynamic_ntk_rope_matches_reference_traces_eager_and_graph():
     """rope_scaling = dynamic (lade/models/modeling_llama.py:292-318) on the HIP step: `lade_rope_rows_dynamic` keeps the reference's
     "longest kv_seq_len seen" on the device and writes the step's cos / sin rows from it - fp32 engine vs the reference's own runs (tables
     rebuilt at nearly every step, one run with non-monotone step lengths), eager and hipGraph (whose padded candidate slots must not count
-    as sequence length), tokens / steps / per-step cache lengths; and a second run on the same engine starts from the original tables again."""
+    as sequence length), tokens / steps / per-step cache lengths.  Each run starts from a fresh model's state (reset_rope_state): the
+    state itself survives reset(), as the reference's does across generate() calls (next test)."""
     from lookaheaddecoding_amd.decoding import LookaheadDecoder
     from lookaheaddecoding_amd.engine import StepEngine
     for run in load("e2e_dynamic_ntk.json")["runs"]:
@@ -289,9 +290,33 @@ def test_dynamic_ntk_rope_matches_reference_traces_eager_and_graph():
         eng = StepEngine(cfg, w, dtype=torch.float32, max_seq=512, max_T=320)
         assert eng.ntk_state is not None and int(eng.ntk_state.item()) == run["max_pos"]
         for use_graph in (False, True, False):
+            eng.reset_rope_state()
             dec = LookaheadDecoder(eng, run["W"], run["N"], run["G"], pool_from_prompt=bool(run["pool_from_prompt"]), use_graph=use_graph)
             out = dec.greedy(run["prompt"], run["max_length"], rng=random.Random(run["seed"]), keep_trace=True)
             assert out.tokens == run["tokens"] and out.steps == run["steps"], (run["model"], use_graph)
             for i, (mine, ref) in enumerate(zip(out.trace, run["trace"])):
                 assert mine["T"] >= len(ref["ids"]) and mine["P_before"] == ref["P"] and mine["first_guess"] == ref["out_argmax"], (i, use_graph)
             assert int(eng.ntk_state.item()) == max(st["step_len"] for st in run["trace"])
+
+
+def test_dynamic_ntk_state_survives_reset_like_the_reference_module():
+    """Two consecutive generate() calls on ONE reference model (tests/golden/e2e_dynamic_ntk_again.json): the rotary module's longest length
+    seen is never reset (lade/models/modeling_llama.py:243-246, :299-316), the second call rotates with the first call's largest base and
+    emits other tokens than a fresh model.  One engine, two greedy() calls == the reference's two calls (eager and hipGraph); after
+    reset_rope_state() the second prompt yields the fresh model's tokens."""
+    from lookaheaddecoding_amd.decoding import LookaheadDecoder
+    from lookaheaddecoding_amd.engine import StepEngine
+    for run in load("e2e_dynamic_ntk_again.json")["runs"]:
+        cfg = make_config(run["model"], max_pos=run["max_pos"], rope_scaling=run["rope_scaling"])
+        w = {k: torch.as_tensor(v) for k, v in random_weights_numpy(cfg, seed=run["model_seed"], std=run["std"]).items()}
+        for use_graph in (False, True):
+            eng = StepEngine(cfg, w, dtype=torch.float32, max_seq=512, max_T=320)
+            for call in run["calls"]:
+                dec = LookaheadDecoder(eng, run["W"], run["N"], run["G"], use_graph=use_graph)
+                out = dec.greedy(call["prompt"], call["max_length"], rng=random.Random(run["seed"]))
+                assert out.tokens == call["tokens"] and out.steps == call["steps"], (run["model"], use_graph)
+            assert int(eng.ntk_state.item()) == max(c["longest_step"] for c in run["calls"])
+            eng.reset_rope_state()
+            c2 = run["calls"][1]
+            out = LookaheadDecoder(eng, run["W"], run["N"], run["G"], use_graph=use_graph).greedy(c2["prompt"], c2["max_length"], rng=random.Random(run["seed"]))
+            assert out.tokens == run["second_call_on_a_fresh_model"]["tokens"] != c2["tokens"]

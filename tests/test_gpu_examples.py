@@ -75,3 +75,28 @@ def test_bench_two_ranks_end_to_end_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["config"]["parallelism"] == "lp2" and d["config"]["shared_gpu"] is True
     assert d["scaling"] == "strong" and d["value"] > 0 and d["step_compression"] >= 1.0
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["T"] < 60          # rank 0's shard of the 60-token step
+    _check_multi_rank_line(d, 2)
+
+
+def _check_multi_rank_line(d, R):
+    """what a scaling run needs to be interpretable (round-4 review): the collective's real span, the BASELINE configuration's expected (flat)
+    curve, and the reference-default configuration - the one that shards - measured by the same ranks in the same line"""
+    assert d["config"]["collective_ranks"] == R and "expected" in d and set(d["expected"]["speedup_vs_one_rank"]) == {"2", "4", "8"}
+    assert "unmeasured" in d["expected"]["status"]
+    lpd = d["lp_default"]
+    assert "error" not in lpd, lpd
+    assert (lpd["W"], lpd["N"], lpd["G"]) == (60, 8, 60) and lpd["value"] > 0 and lpd["ms_per_step"] > 0 and lpd["step_compression"] >= 1.0
+    assert len(lpd["rows_per_rank_cold"]) == R and max(lpd["rows_per_rank_cold"]) < lpd["rows_one_rank_cold"] == 420
+    assert lpd["expected_speedup_vs_one_rank"] == {"2": 1.45, "4": 1.65, "8": 2.17}
+
+
+def test_bench_eight_ranks_end_to_end_on_one_gpu():
+    """the same with EIGHT ranks - the world size the driver's scaling run ends at: window columns 15 / 8 -> 2 per rank (the last rank gets 1),
+    candidates sharded eight ways, rank 0's kernel decisions adopted by seven others; the line carries both configurations."""
+    out = _run(["bench.py", "--gpus", "8", "--layers", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--prompt-len", "256"],
+               {"LADE_BENCH_SHARE_GPU": "1", "LADE_BENCH_BACKEND": "gloo"})
+    lines = [l for l in out.splitlines() if l.strip()]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 8 and d["steps"] == 3 and d["config"]["parallelism"] == "lp8" and d["config"]["shared_gpu"] is True
+    assert d["scaling"] == "strong" and d["value"] > 0 and d["roofline"]["bound"] == "hbm" and d["roofline"]["T"] <= 16
+    _check_multi_rank_line(d, 8)

@@ -340,6 +340,36 @@ def test_argmax_epilogue_returns_the_ids_of_argmax_over_the_materialised_logits(
                   cabi.dtype_code(a))
 
 
+def test_argmax_nan_rule_is_torchs_in_all_three_kernels():
+    """torch.argmax treats NaN as the maximum (the first NaN of a row wins).  lade_argmax_rows, the lm_head GEMM's argmax epilogue and
+    lade_argmax_pairs follow the same rule, so that a step with the fused tail surfaces a NaN logit exactly where the unfused one does
+    (round-4 advice: the epilogue's `v > best` never selected a NaN).  And the C ABI refuses an argmax epilogue whose column block it would
+    have to narrow silently (the pair buffer's stride is the caller's ceil(N / bn))."""
+    from lookaheaddecoding_amd import ops
+    torch.manual_seed(5)
+    K, V, M = 256, 1000, 40
+    w = (torch.randn(V, K, device="cuda") * 0.05).bfloat16()
+    a = torch.randn(M, K, device="cuda").bfloat16()
+    a[3, 5] = float("nan")                                 # row 3: every logit is NaN -> column 0
+    w[700, 9] = float("nan")                               # column 700 is NaN for every (finite) row
+    w[123, 9] = float("nan")                               # ... and so is column 123: the lower one wins
+    for ww in (w, ops.to_ktile(w)):
+        logits = ops.gemm_skinny(a, ww, n_split=1, bn=128, mb=2)
+        want_t = torch.argmax(logits.float(), dim=-1).to(torch.int32)
+        assert int(want_t[3]) == 0 and int(want_t[0]) == 123
+        assert torch.equal(ops.argmax_rows(logits), want_t)
+        for bn in (64, 96, 128, 256):
+            got = torch.full((M,), -1, dtype=torch.int32, device="cuda")
+            ops.gemm_argmax(a, ww, got, bn=bn, mb=2)
+            assert torch.equal(got, want_t), (bn, ww.dim())
+    lf = torch.randn(5, 333, device="cuda")
+    lf[2, 40] = float("nan"); lf[2, 17] = float("nan"); lf[4, 0] = float("inf")
+    assert torch.equal(ops.argmax_rows(lf), torch.argmax(lf, dim=-1).to(torch.int32))
+    with pytest.raises(cabi.LadeHipError, match="epilogue 2"):
+        cabi.call("lade_gemm_skinny", cabi.ptr(a), K, cabi.ptr(w), K, None, 0, cabi.ptr(torch.empty(4096, device="cuda")), M, V, K, 1, 256, 6, 0, 0, 0, 2,
+                  cabi.dtype_code(a))
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
 def test_embed_rmsnorm_is_the_row_gather_followed_by_the_norm_bit_for_bit(dtype):
     """lade_embed_rmsnorm (embedding lookup inside the first layer's input norm; modeling_llama.py:1413 + :857) against

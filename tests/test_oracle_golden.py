@@ -157,6 +157,23 @@ def test_dynamic_ntk_rope_matches_reference_traces():
     assert any(differs)            # (a run whose tiny model is insensitive to the rotation may coincide; not both)
 
 
+def test_dynamic_ntk_state_persists_across_calls_like_the_reference_module():
+    """Two consecutive generate() calls on ONE reference model (tests/golden/e2e_dynamic_ntk_again.json): `max_seq_len_cached` and the rebuilt
+    inv_freq live on the rotary module and are never reset (lade/models/modeling_llama.py:243-246, :299-316), so the second call rotates with
+    the largest base the first one reached - and emits OTHER tokens than a fresh model would.  The oracle's model object keeps the state
+    the same way."""
+    d = load("e2e_dynamic_ntk_again.json")
+    assert len(d["runs"]) == 2
+    for run in d["runs"]:
+        model = oracle_model(run)
+        for call in run["calls"]:
+            res = O.lookahead_greedy(model, call["prompt"], run["W"], run["N"], run["G"], call["max_length"], random.Random(run["seed"]))
+            assert res.tokens == call["tokens"] and res.steps == call["steps"], run["model"]
+        c2 = run["calls"][1]
+        fresh = O.lookahead_greedy(oracle_model(run), c2["prompt"], run["W"], run["N"], run["G"], c2["max_length"], random.Random(run["seed"]))
+        assert fresh.tokens == run["second_call_on_a_fresh_model"]["tokens"] and fresh.tokens != c2["tokens"]
+
+
 def test_lookahead_parallel_matches_reference_gloo_runs():
     d = load("e2e_lp.json")
     for run in d["runs"]:

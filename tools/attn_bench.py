@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--resident", action="store_true", help="one K/V cache, re-read every repetition (stays in the Infinity Cache)")
     ap.add_argument("--lp-rank", action="store_true", help="a lookahead-parallel rank's step instead of the full window: 4 re-fed inputs, "
                     "columns 12..14 of the W=15 window, 2 candidates (T = 31; with --H 64 --Hkv 8 this is config 5's rank shape)")
+    ap.add_argument("--wg", type=int, default=0, help="work-group rows (lade_attn_args.wg_rows): 0 = default, 128 | 64 | 32")
     ap.add_argument("--W", type=int, default=15)
     ap.add_argument("--N", type=int, default=5)
     a = ap.parse_args()
@@ -61,8 +62,8 @@ def main():
                     print("   stamps (cycles since WG start) mean:", [int(x) for x in rel.mean(0).tolist()], "max:", [int(x) for x in rel.max(0)[0].tolist()],
                           " WG start spread:", int(tl[:, 0].max() - tl[:, 0].min()), " kernel span:", int(tl[:, 6].max() - tl[:, 0].min()))
                 else:
-                    us = ops.time_attn(q, k, vt, mask, H=a.H, Hkv=a.Hkv, d=a.d, n_splits=n, reps=a.reps)
-                print(f"H={a.H:3d}/{a.Hkv:2d} T={T:4d} P={P:5d} splits={n:3d}  {us:8.2f} us   {alg / us / 1e3:8.1f} GB/s  ({alg / us / 1e3 / 8000 * 100:5.1f}% of 8 TB/s)", flush=True)
+                    us = ops.time_attn(q, k, vt, mask, H=a.H, Hkv=a.Hkv, d=a.d, n_splits=n, reps=a.reps, wg_rows=a.wg)
+                print(f"H={a.H:3d}/{a.Hkv:2d} T={T:4d} P={P:5d} splits={n:3d} wg={a.wg or 128:3d}  {us:8.2f} us   {alg / us / 1e3:8.1f} GB/s  ({alg / us / 1e3 / 8000 * 100:5.1f}% of 8 TB/s)", flush=True)
 
 
 if __name__ == "__main__":

@@ -1,6 +1,6 @@
 """Summarises two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, as MI355X_MICROARCH.md prescribes)
 of tools/attn_bench.py into profiles/r1_attn_pmc.json:
-    python tools/pmc_summary.py fetch.csv write.csv T P n_splits out.json [H Hkv d]
+    python tools/pmc_summary.py fetch.csv write.csv T P n_splits out.json [H Hkv d [wg_rows]]
 FETCH_SIZE is doubled (gfx950 reports 1/2 of wide coalesced reads), WRITE_SIZE is taken as is; KiB -> bytes."""
 import collections
 import csv
@@ -23,7 +23,8 @@ fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
 T, P, ns = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 H, Hkv, d = (int(sys.argv[7]), int(sys.argv[8]), int(sys.argv[9])) if len(sys.argv) > 9 else (32, 32, 128)
 alg = 2 * (2 * Hkv * (P + T) * d + 2 * H * T * d)
-entry = {"H": H, "Hkv": Hkv, "d": d, "T": T, "P": P, "n_splits": ns,
+wg = int(sys.argv[10]) if len(sys.argv) > 10 else 128
+entry = {"H": H, "Hkv": Hkv, "d": d, "T": T, "P": P, "n_splits": ns, "wg_rows": wg,
          "fetch_kib_raw": fetch, "write_kib_raw": write,
          "traffic_bytes": int((2 * (fetch.get("fwd", 0) + fetch.get("combine", 0)) + write.get("fwd", 0) + write.get("combine", 0)) * 1024),
          "algorithmic_bytes": alg,
