@@ -806,7 +806,10 @@ class StepEngine:
             times = measure(self._attn_candidates(mclass, T, P + T), apply_attn)
             if times:
                 best = min(times, key=times.get)
-                pick = best if times[best] < times.get(inc, float("inf")) * 0.997 else inc
+                # (a challenger must win by > 1 %: the candidates of this coordinate lie within a fraction of a per cent of each other on most
+                # shapes - first round-5 runs flipped between 6 and 8 splits from box to box on 0.2-0.6 % - and more splits mean more partial
+                # traffic for nothing)
+                pick = best if times[best] < times.get(inc, float("inf")) * 0.99 else inc
                 self.attn_cfg[mclass] = choice["attn"] = tuple(pick)
                 log["attn"] = {"default": inc, "in_step_choice": pick, "ms_per_layer_default": round(times.get(inc, float("nan")), 5),
                                "ms_per_layer_in_step_choice": round(times[pick], 5), "candidates": len(times), "probe_context": ctx,
