@@ -151,9 +151,15 @@ typedef struct lade_attn_args {
     const float* qkv_parts; /* [n_parts][T][(H + 2 Hkv) d], part_stride elements apart */
     int64_t part_stride;
     const int32_t* positions;   /* [T] position ids (rows of the tables), or null: token t uses table row t (per-step gathered rows) */
-    const void* cos_tab;    /* [max_pos][d], model dtype */
+    const void* cos_tab;    /* [max_pos][d], model dtype; the fused form needs tables whose two halves are equal (emb = cat(freqs, freqs)) */
     const void* sin_tab;
     int32_t max_pos;
+    /* Producer mode of the fused form (non-null; needs n_splits > 1 and `q`): instead of every KV split rebuilding its head's q rows, the
+     * first work-groups of the grid do the RoPE + append work ONCE per (KV head, 32 tokens) - rotated q rows to `q`, K / V rows to the
+     * caches, write-through - and raise sync_flags[kvh]; the attention work-groups of that head request the cache tiles that hold no new
+     * row, poll the flag from one lane (bounded: a launch never hangs) and then fetch q and the other tiles.  sync_flags: device
+     * int32[Hkv], zero before the first launch; lade_attn_combine (which must follow) zeroes it again. */
+    int32_t* sync_flags;
 } lade_attn_args;
 
 int lade_attn_fwd(const lade_attn_args* a, void* stream);

@@ -52,7 +52,8 @@ class AttnArgs(C.Structure):
                 ("dtype", C.c_int32), ("n_splits", C.c_int32), ("scale", C.c_float), ("mask", MaskParams),
                 # ABI 2: work-group shape + fused RoPE / KV append (all zero = the ABI-1 behaviour)
                 ("wg_rows", C.c_int32), ("n_parts", C.c_int32), ("qkv_parts", C.c_void_p), ("part_stride", C.c_int64),
-                ("positions", C.c_void_p), ("cos_tab", C.c_void_p), ("sin_tab", C.c_void_p), ("max_pos", C.c_int32)]
+                ("positions", C.c_void_p), ("cos_tab", C.c_void_p), ("sin_tab", C.c_void_p), ("max_pos", C.c_int32),
+                ("sync_flags", C.c_void_p)]
 
 
 _lib: Optional[C.CDLL] = None

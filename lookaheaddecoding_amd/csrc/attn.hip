@@ -62,6 +62,10 @@ struct AttnK {
     uint16_t* k_w;               // the caches again, writable
     uint16_t* vt_w;
     int n_parts, max_pos, row_w;
+    // producer mode of the fused form (sync_flags given): the first n_prod work-groups of the grid do lade_rope_kv_append_parts' work ONCE per KV head
+    // (32 tokens each) and raise flags[kvh]; the attention work-groups of that head request the cache tiles that hold no new row, then wait for the flag
+    int32_t* flags;
+    int n_prod, prod_chunks;
 };
 
 // ---- 1-D grid, XCD aware ---------------------------------------------------------------------------------------------------------
@@ -76,7 +80,7 @@ __device__ __forceinline__ uint32_t div_magic(uint32_t x, uint32_t magic) { retu
 
 struct BlockId { int rb, kvh, sp, group; bool live; };
 __device__ __forceinline__ BlockId block_decode(const AttnK& a) {
-    const uint32_t b = blockIdx.x;
+    const uint32_t b = blockIdx.x - (uint32_t)a.n_prod;          // (n_prod is a multiple of 8: b mod 8 = the XCD of the block stays what it was)
     const uint32_t x = b & 7u, j = b >> 3;
     const uint32_t q = div_magic(j, a.ns_magic);
     BlockId r;
@@ -344,6 +348,85 @@ __device__ __forceinline__ void rope_apply(const RopeItem<NPC>& it, int n_parts,
     }
 }
 
+// ---- producer mode of the fused form ---------------------------------------------------------------------------------------------------
+// The first form above makes every KV split of a head rebuild the head's q rows from fp32 partials (+15.6 MB into the start-of-launch
+// burst: measured +3.7 us per layer).  Here lade_rope_kv_append_parts' work is done ONCE - by dedicated work-groups at the head of the
+// grid, one per (KV head, 32 tokens) - and handed to the attention work-groups of that head INSIDE the launch: the producer writes the
+// rotated q rows (to the caller's q buffer), the K rows and the V^T columns with WRITE-THROUGH stores (sc0 sc1: the bytes leave the XCD's
+// L2 as they are issued), drains them (s_waitcnt vmcnt(0) - inline asm, so that the compiler cannot drop it), and bumps flags[kvh]
+// (relaxed, device scope).  A consumer polls the flag from ONE lane (relaxed sc1 loads, s_sleep between them, bounded), passes a
+// barrier and only then requests q and the tiles that hold new rows - with sc1 loads, the consumer side of the guide's
+// {write-through stores / sc1 loads} form (MI355X_MICROARCH.md, inter-workgroup visibility); everything it requested before
+// (the tiles of the cache proper) does not depend on the producers.  Dispatch order is not relied upon for correctness: a consumer whose
+// flag never comes (the producers queued behind a full chip) gives up after ~0.1 s and the launch ends - wrong results instead of
+// a hung GPU; the producers sit at the head of the grid so that in practice they are resident first.  flags[] is reset by
+// lade_attn_combine (this form needs n_splits > 1), so the buffer only has to be zero before the first launch.
+__device__ __forceinline__ void store_wt_b128(void* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void store_wt_b16(void* p, uint32_t v) { asm volatile("global_store_short %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+
+constexpr int PROD_TOK = 32;           // tokens per producer work-group
+
+template <typename T, int D, int NPC, int NTHR>
+__device__ __forceinline__ void rope_producer(const AttnK& a, unsigned char* smem) {
+    constexpr int VPH = D / 16, LDV = D + 2;
+    const int tid = threadIdx.x;
+    const int pb = blockIdx.x;
+    const int kvh = pb / a.prod_chunks, ch = pb - kvh * a.prod_chunks;
+    if (kvh >= a.Hkv) return;                                   // padding of the producer range to a multiple of 8
+    int P = a.m.P;
+    if (a.dyn_P) P = *a.dyn_P;
+    const int t0 = ch * PROD_TOK, nt_ = min(PROD_TOK, a.m.T - t0);
+    const int n_rep = a.n_rep;
+    const bool writes = P + a.m.T <= a.S_max;                   // (a device-side cache length past the cache: nothing is written, as in lade_rope_kv_append)
+    uint16_t* q_out = const_cast<uint16_t*>(a.q);
+    if (writes) {
+        // q rows of the group's heads + the K row: one item = 8 + 8 values (columns i.., i + D/2..) of one head row
+        const int per_tok = (n_rep + 1) * VPH;
+        for (int idx = tid; idx < nt_ * per_tok; idx += NTHR) {
+            const int tt = idx / per_tok, rem = idx - tt * per_tok, hs = rem / VPH, i = (rem - hs * VPH) * 8;
+            const int t = t0 + tt;
+            int trow = t;
+            if (a.positions) { trow = a.positions[t]; trow = trow < 0 ? 0 : (trow >= a.max_pos ? a.max_pos - 1 : trow); }
+            const size_t col = hs < n_rep ? (size_t)(kvh * n_rep + hs) * D : (size_t)(a.H + kvh) * D;
+            RopeItem<NPC> it;
+            rope_load<NPC, D>(it, a, (size_t)t * a.row_w + col + i, trow, i);
+            u32x4 o1, o2;
+            rope_apply<T, NPC>(it, a.n_parts, o1, o2);
+            uint16_t* dst = hs < n_rep ? q_out + (size_t)t * a.q_row_stride + (size_t)(kvh * n_rep + hs) * D + i
+                                       : a.k_w + ((size_t)kvh * a.S_max + P + t) * D + i;
+            store_wt_b128(dst, o1);
+            store_wt_b128(dst + D / 2, o2);
+        }
+        // V rows: partials summed in split order, rounded once, transposed through LDS ([token][d], padded rows)
+        uint16_t* stage_v = reinterpret_cast<uint16_t*>(smem);
+        const size_t v_col = (size_t)(a.H + a.Hkv + kvh) * D;
+        for (int idx = tid; idx < nt_ * (D / 4); idx += NTHR) {
+            const int tt = idx / (D / 4), d4 = (idx - tt * (D / 4)) * 4;
+            const size_t e0 = (size_t)(t0 + tt) * a.row_w + v_col + d4;
+            float4 vp[NPC];
+#pragma unroll
+            for (int j = 0; j < NPC; ++j) vp[j] = *reinterpret_cast<const float4*>(a.parts + (size_t)min(j, a.n_parts - 1) * a.part_stride + e0);
+            float4 acc = float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NPC; ++j)
+                if (j < a.n_parts) { acc.x += vp[j].x; acc.y += vp[j].y; acc.z += vp[j].z; acc.w += vp[j].w; }
+            uint32_t* dst = reinterpret_cast<uint32_t*>(stage_v + tt * LDV + d4);
+            dst[0] = (uint32_t)from_f32<T>(acc.x) | ((uint32_t)from_f32<T>(acc.y) << 16);
+            dst[1] = (uint32_t)from_f32<T>(acc.z) | ((uint32_t)from_f32<T>(acc.w) << 16);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wg_barrier();
+        for (int idx = tid; idx < D * PROD_TOK; idx += NTHR) {
+            const int dd = idx / PROD_TOK, tt = idx - dd * PROD_TOK;
+            if (tt < nt_) store_wt_b16(a.vt_w + ((size_t)kvh * D + dd) * a.S_max + P + t0 + tt, stage_v[tt * LDV + dd]);
+        }
+    }
+    // every store of this wave has left the chip's caches; then the barrier; then ONE arrival per work-group
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wg_barrier();
+    if (tid == 0) __hip_atomic_fetch_add(a.flags + kvh, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Work split inside a work-group of RG x KQ waves: wave (rg, kq) owns query rows [32*rg, 32*rg+32) of the block and the
 // 32-key part kq of every stage; a stage is KQ/2 tiles of 64 keys.  Three shapes are built:
 //   RG=4, KQ=2 (8 waves, 128 rows, stage = 1 tile,  3-stage ring)   steps of more than 64 (head-in-group, token) rows
@@ -377,6 +460,13 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
     // LDS: [ring of NSTG stages of TPS x (K tile | V^T tile)] [Q tile]; the ring is reused for the merge + store staging
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* q_lds = smem + NSTG * STAGE_BYTES;
+    if constexpr (NPC > 0) {
+        if ((int)blockIdx.x < a.n_prod) {               // producer mode: the head of the grid does the RoPE + append work once per KV head
+            rope_producer<T, D, NPC, NTHR>(a, smem);
+            return;
+        }
+    }
+    const bool pmode = NPC > 0 && a.n_prod > 0;         // ... and this work-group waits for its head's flag before it touches q or a new row
     dbg_stamp(a, 0);
 
     const int tid = threadIdx.x;
@@ -420,7 +510,8 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
         if (r < n_rows) { split_row(r, hg, t); return 1; }
         return rbk * ROWS + (row & ~31) < n_rows ? 2 : 0;
     };
-    if constexpr (NPC == 0) {
+    auto issue_q = [&](auto sc1_c) {
+        constexpr int AUX = decltype(sc1_c)::value ? 16 : 0;      // sc1: served by L2 / memory, never by this CU's L1 (producer mode)
 #pragma unroll
         for (int i = 0; i < QPW; ++i) {
             const int piece = wave * QPW + i;
@@ -434,9 +525,12 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
             split_row(r, hg, t);
             const uint16_t* src = a.q + (size_t)t * a.q_row_stride + (size_t)(kvh * n_rep + hg) * D + c * 8;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(q_lds + piece * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(q_lds + piece * 1024), 16, 0, AUX);
         }
-    } else {
+    };
+    if constexpr (NPC == 0) {
+        issue_q(std::false_type{});
+    } else if (!pmode) {
         // fused: the q rows of this block as fp32 partials of the qkv projection + their cos / sin rows, requested before anything that
         // depends on the cache length; rotated and written to the Q tile further down, behind the K / V requests
 #pragma unroll
@@ -490,7 +584,8 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
     }
     const unsigned char* kbytes = reinterpret_cast<const unsigned char*>(kbase);
     const unsigned char* vbytes = reinterpret_cast<const unsigned char*>(vbase);
-    auto issue_tiles = [&](int stage, int ts, int tile) {
+    auto issue_tiles_aux = [&](int stage, int ts, int tile, auto sc1_c) {
+        constexpr int AUX = decltype(sc1_c)::value ? 16 : 0;
         const int k0 = min(tile, last_tile) * KT;
         unsigned char* ks = smem + stage * STAGE_BYTES + ts * TILE_BYTES;
         unsigned char* vs = ks + K_BYTES;
@@ -500,14 +595,19 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
         for (int i = 0; i < KPW; ++i) {
             const int piece = wave * KPW + i;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kt + k_off[i]),
-                                             (__attribute__((address_space(3))) void*)(ks + piece * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(ks + piece * 1024), 16, 0, AUX);
         }
 #pragma unroll
         for (int i = 0; i < VPW; ++i) {
             const int piece = wave * VPW + i;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vt + v_off[i]),
-                                             (__attribute__((address_space(3))) void*)(vs + piece * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(vs + piece * 1024), 16, 0, AUX);
         }
+    };
+    int sc1_from_q = 1 << 30;            // producer mode: tiles (offsets within the split) from this one on hold rows a producer wrote in THIS launch: sc1 loads
+    auto issue_tiles = [&](int stage, int ts, int tile) {
+        if (NPC > 0 && tile - base >= sc1_from_q) issue_tiles_aux(stage, ts, tile, std::true_type{});
+        else issue_tiles_aux(stage, ts, tile, std::false_type{});
     };
     const int nt = (my_tiles + TPS - 1) / TPS;                                  // stages
     const int nt_issued = max(nt, NSTG);                                        // the first NSTG stages are always in flight
@@ -518,12 +618,38 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
 #pragma unroll
         for (int ts = 0; ts < TPS; ++ts) issue_tiles(stage, ts, tile_of(j, ts));
     };
+    bool pm_wait_all = false;            // producer mode: q was requested AFTER the first stages - the loop's first wait covers everything
     int store_fence_at = -1;             // fused: the loop iteration behind which the first tile holding a row this work-group stored is requested
     if constexpr (NPC == 0) {
 #pragma unroll
         for (int s = 0; s < NSTG; ++s) issue_stage(s, s);
     } else {
         // ---- fused RoPE + KV append ----
+        if (pmode) {
+            // producer mode: the ring stages that hold no new row are requested at once; q and the others after this KV head's flag
+            const int first_new_q = m.P / KT - base;       // tile (within the split) of the first new key; <= 0: the split starts inside the new rows
+            int early = 0;
+#pragma unroll
+            for (int s = 0; s < NSTG; ++s) {
+                const int last_q = s * TPS < my_tiles ? min(s * TPS + TPS - 1, my_tiles - 1) : 0;
+                if (early == s && last_q < first_new_q) early = s + 1;
+            }
+            if (early == NSTG) {
+#pragma unroll
+                for (int s = 0; s < NSTG; ++s) issue_stage(s, s);
+            } else {
+                for (int s = 0; s < early; ++s) issue_stage(s, s);
+            }
+            if (tid == 0) {                          // ONE lane polls (relaxed, device scope: an sc1 load), bounded: ~0.1 s, then the launch ends wrong rather than never
+                int spins = 0;
+                while (__hip_atomic_load(a.flags + kvh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.prod_chunks && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(2);
+            }
+            wg_barrier();
+            sc1_from_q = first_new_q;                // from here on the tiles that hold new rows are requested with sc1 loads
+            issue_q(std::true_type{});
+            for (int s = early; s < NSTG; ++s) issue_stage(s, s);
+            pm_wait_all = true;
+        } else {
         // the rows P .. P+T of K and V^T that fall into this work-group's key range are its own to produce: key k_lo .. k_hi
         const int k_lo = max(m.P, base * KT), k_hi = min(S_tot, (base + my_tiles) * KT);
         const int n_new = S_tot <= a.S_max ? max(0, k_hi - k_lo) : 0;         // (a device-side cache length past the cache: nothing is written, as in lade_rope_kv_append)
@@ -645,6 +771,7 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
                 for (int s = 0; s < NSTG; ++s) issue_stage(s, s);
             }
         }
+        }
     }
     dbg_stamp(a, 1);
 
@@ -672,7 +799,8 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
         const unsigned char* vs = ks + K_BYTES;
         // wait for stage i (and, the first time, the older Q pieces): the pieces of the younger stages stay in flight
         const int younger = min(nt_issued, i + NSTG) - (i + 1);
-        if (younger >= 2) wait_vm<2 * PIECES>();
+        if (NPC > 0 && pm_wait_all && i == 0) wait_vm<0>();
+        else if (younger >= 2) wait_vm<2 * PIECES>();
         else if (younger == 1) wait_vm<PIECES>();
         else wait_vm<0>();
         wg_barrier();
@@ -951,6 +1079,11 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnK a, int D) {
     ld.po_stride = (size_t)Tn * a.H * D;
     const u32x4 wv = merge_splits<T>(a.n_splits, ld);
     *reinterpret_cast<u32x4*>(a.out + (size_t)t * a.out_row_stride + (size_t)qh * D + d0) = wv;
+    // producer mode of the fused form: every attention work-group of the launch before this one is done - the flags are zero again for the next
+    if (a.flags && blockIdx.x == 0 && blockIdx.y == 0) {
+        const int lt = threadIdx.y * blockDim.x + threadIdx.x;
+        if (lt < a.Hkv) a.flags[lt] = 0;
+    }
 }
 
 // ---- fp32 path: plain VALU kernel (parity / tiny models; not a BASELINE dtype) -------------
@@ -1024,6 +1157,10 @@ static int validate(const lade_attn_args* a) {
         LADE_REQUIRE(a->positions || a->max_pos >= a->mask.T, LADE_E_ARG, "lade_attn: fused RoPE without positions reads table rows 0..T-1 (max_pos=%d, T=%d)", a->max_pos, a->mask.T);
         LADE_REQUIRE(a->dtype == LADE_BF16 || a->dtype == LADE_F16, LADE_E_DTYPE, "lade_attn: fused RoPE is built for bf16 / f16 (dtype=%d)", a->dtype);
         LADE_REQUIRE(a->part_stride >= (int64_t)a->mask.T * (a->H + 2 * a->Hkv) * a->d, LADE_E_ARG, "lade_attn: part_stride %lld is shorter than one partial", (long long)a->part_stride);
+        LADE_REQUIRE(!a->sync_flags || (a->q && a->n_splits > 1 && a->q_row_stride % 8 == 0), LADE_E_ARG,
+                     "lade_attn: the producer mode of the fused RoPE (sync_flags) writes the rotated q rows to `q` and is reset by lade_attn_combine: it needs q and n_splits > 1");
+    } else {
+        LADE_REQUIRE(!a->sync_flags, LADE_E_ARG, "lade_attn: sync_flags without the fused RoPE (n_parts = 0)");
     }
     if (!a->mask.is_prefill) {
         const lade_mask_params& m = a->mask;
@@ -1058,6 +1195,9 @@ static AttnK make_k(const lade_attn_args* a) {
     k.cos_tab = (const uint16_t*)a->cos_tab; k.sin_tab = (const uint16_t*)a->sin_tab;
     k.k_w = (uint16_t*)a->k_cache; k.vt_w = (uint16_t*)a->vt_cache;
     k.n_parts = a->n_parts; k.max_pos = a->max_pos; k.row_w = (a->H + 2 * a->Hkv) * a->d;
+    k.flags = a->n_parts ? a->sync_flags : nullptr;
+    k.prod_chunks = cdiv(a->mask.T, PROD_TOK);
+    k.n_prod = k.flags ? 8 * cdiv(a->Hkv * k.prod_chunks, 8) : 0;
     return k;
 }
 
@@ -1067,7 +1207,7 @@ static int launch_fwd_shape(const lade_attn_args* a, hipStream_t st) {
     const int n_rep = a->H / a->Hkv;
     constexpr int ROWS = 32 * RG, TPS = KQ / 2, NSTG = TPS == 1 ? 3 : 2;
     k.n_groups = cdiv(n_rep * a->mask.T, ROWS) * a->Hkv;
-    dim3 grid(8 * cdiv(k.n_groups, 8) * a->n_splits);       // block_decode: b = x + 8 (q n_splits + sp), group = x + 8 q
+    dim3 grid(k.n_prod + 8 * cdiv(k.n_groups, 8) * a->n_splits);       // [producers |] block_decode: b = x + 8 (q n_splits + sp), group = x + 8 q
     const size_t lds = (size_t)KT * D * 2 * 2 * TPS * NSTG + (size_t)ROWS * D * 2;
     static bool attr_set = false;          // > 64 KiB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set) {

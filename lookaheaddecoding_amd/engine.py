@@ -175,7 +175,7 @@ class StepEngine:
         # layer at the 7B step - every split re-reads the q rows as fp32 partials; LADE_FUSE_ROPE=1 makes it the default, the
         # in-step pass always tries both), the 128-row shape, the sqrt split rule
         self.attn_cfg = {}
-        self.attn_default = (1 if os.environ.get("LADE_FUSE_ROPE", "0") == "1" else 0, 128, 0)
+        self.attn_default = (int(os.environ.get("LADE_FUSE_ROPE", "0")) if os.environ.get("LADE_FUSE_ROPE", "0") in ("1", "2") else 0, 128, 0)
         self.step_tune_log = {}             # row class -> what the in-step pass measured (bench.py prints it)
         self._alloc_workspaces(max_T)
         try:
@@ -349,6 +349,8 @@ class StepEngine:
         if self.custom_gemm:
             self.ws_part = torch.empty(16 * 128 * max(qkv_w, 2 * self.inter, self.hidden), dtype=torch.float32, device=dev)
             self.ws_q = torch.empty(max_T, self.H * self.d, dtype=dt, device=dev)
+            if getattr(self, "attn_flags", None) is None:          # producer mode of the fused RoPE: one arrival counter per KV head, zero between launches
+                self.attn_flags = torch.zeros(max(64, self.Hkv), dtype=torch.int32, device=dev)
 
     def grow(self, max_seq: int, max_T: int, keep_rows: int = 0) -> None:
         """Enlarges the KV cache and / or the step workspaces in place (the fused weights stay): the first keep_rows cache
@@ -721,7 +723,7 @@ class StepEngine:
         if os.environ.get("LADE_ATTN_TUNE", "1") == "0":
             return [inc]
         qkv = self.gemm_cfg.get(("wqkv", mclass))
-        fuses = (1, 0) if (qkv is not None and qkv[2] <= 4 and os.environ.get("LADE_FUSE_ROPE", "") != "off") else (0,)
+        fuses = (2, 1, 0) if (qkv is not None and qkv[2] <= 4 and os.environ.get("LADE_FUSE_ROPE", "") != "off") else (0,)
         rows = (self.H // self.Hkv) * T
         shapes = [128, 64] + ([32] if rows <= 64 or self.H != self.Hkv else [])
         out, seen = [], set()
@@ -937,9 +939,12 @@ class StepEngine:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e0.record()
             if fuse_rope:
-                # q and the new K / V rows straight from the qkv GEMM's partials: no RoPE launch (same bits as the two-launch form)
-                ops.attn_fwd(None, self.k_cache(li), self.vt_cache(li), mask, H=H, Hkv=Hkv, d=d, out=o, n_splits=n_splits, part_o=self.part_o,
-                             part_ml=self.part_ml, dyn_P=dyn_P, wg_rows=acfg[1], qkv_parts=part, n_parts=cfg_qkv[2], positions=rpos, cos=rcos, sin=rsin)
+                # q and the new K / V rows straight from the qkv GEMM's partials: no RoPE launch (same bits as the two-launch form).  Mode 2:
+                # dedicated work-groups of the launch produce them once per KV head and hand them over through sync_flags
+                prod = acfg[0] == 2 and n_splits > 1
+                ops.attn_fwd(qb if prod else None, self.k_cache(li), self.vt_cache(li), mask, H=H, Hkv=Hkv, d=d, out=o, n_splits=n_splits, part_o=self.part_o,
+                             part_ml=self.part_ml, dyn_P=dyn_P, wg_rows=acfg[1], qkv_parts=part, n_parts=cfg_qkv[2], positions=rpos, cos=rcos, sin=rsin,
+                             sync_flags=self.attn_flags if prod else None)
             elif not self.skip_attn:
                 ops.attn_fwd(q_in, self.k_cache(li), self.vt_cache(li), mask, H=H, Hkv=Hkv, d=d, out=o, n_splits=n_splits,
                              part_o=self.part_o, part_ml=self.part_ml, dyn_P=dyn_P, wg_rows=acfg[1])

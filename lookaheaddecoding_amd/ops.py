@@ -100,14 +100,17 @@ def attn_fwd(q: Optional[torch.Tensor], k_cache: torch.Tensor, vt_cache: torch.T
              out: Optional[torch.Tensor] = None, n_splits: Optional[int] = None, scale: Optional[float] = None,
              q_row_stride: Optional[int] = None, part_o: Optional[torch.Tensor] = None, part_ml: Optional[torch.Tensor] = None,
              dyn_P: Optional[torch.Tensor] = None, wg_rows: int = 0, qkv_parts: Optional[torch.Tensor] = None, n_parts: int = 0,
-             positions: Optional[torch.Tensor] = None, cos: Optional[torch.Tensor] = None, sin: Optional[torch.Tensor] = None) -> torch.Tensor:
+             positions: Optional[torch.Tensor] = None, cos: Optional[torch.Tensor] = None, sin: Optional[torch.Tensor] = None,
+             sync_flags: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Lookahead attention for one step.  q: [T, >=H*d] rows (token stride q_row_stride elements, default
     q.stride(0)); k_cache [Hkv, S_max, d]; vt_cache [Hkv, d, S_max]; returns out [T, H*d].
     wg_rows: work-group shape (0 = default, 32 | 64 | 128 query rows per work-group).
     Fused RoPE + KV append (qkv_parts given): q is not read; q and the new K / V rows P..P+T come from the qkv projection's n_parts (1..4)
     fp32 split-K partials `qkv_parts` ([>= n_parts][T][(H + 2 Hkv) d] with stride qkv_parts.stride(0), or flat with stride T (H + 2 Hkv) d), rotated with the
     cos / sin rows positions[t] (positions None: row t) - the rows are written to the caches and the result equals
-    rope_kv_append_parts + attn_fwd bit for bit."""
+    rope_kv_append_parts + attn_fwd bit for bit.  sync_flags (device int32 [>= Hkv], zero before the first launch; needs q = a [T, H*d]
+    buffer and n_splits > 1): the producer mode of the fused form - dedicated work-groups do the RoPE + append work once per KV head
+    and hand it to the attention work-groups inside the launch (include/lade_hip.h)."""
     for n, t in (("k_cache", k_cache), ("vt_cache", vt_cache)):
         _dev(t, n)
     T = mask.T
@@ -124,9 +127,11 @@ def attn_fwd(q: Optional[torch.Tensor], k_cache: torch.Tensor, vt_cache: torch.T
         part_stride = qkv_parts.stride(0) if qkv_parts.dim() == 3 else T * row_w
         assert qkv_parts.numel() >= (n_parts - 1) * part_stride + T * row_w
         _check_rope_halves(cos, sin)
+        if sync_flags is not None:
+            assert q is not None and q.dtype == dt and q.stride(-1) == 1 and sync_flags.dtype == torch.int32 and sync_flags.numel() >= Hkv
     else:
         _dev(q, "q")
-        assert q.stride(-1) == 1 and q.dtype == dt
+        assert q.stride(-1) == 1 and q.dtype == dt and sync_flags is None
     dev = k_cache.device
     if out is None:
         out = torch.empty(T, H * d, dtype=dt, device=dev)
@@ -145,6 +150,7 @@ def attn_fwd(q: Optional[torch.Tensor], k_cache: torch.Tensor, vt_cache: torch.T
     if fused:
         a.n_parts, a.qkv_parts, a.part_stride = int(n_parts), ptr(qkv_parts), int(part_stride)
         a.positions, a.cos_tab, a.sin_tab, a.max_pos = ptr(positions), ptr(cos), ptr(sin), int(cos.shape[0])
+        a.sync_flags = ptr(sync_flags)
     call("lade_attn_fwd", C.byref(a))
     if n_splits > 1:
         call("lade_attn_combine", C.byref(a))

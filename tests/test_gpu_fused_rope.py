@@ -53,11 +53,28 @@ def _case(H, Hkv, d, T, P, n_parts, n_splits, wg, dtype, mask, seed, use_pos=Tru
                         positions=rpos, cos=rcos, sin=rsin)
     torch.cuda.synchronize()
     tag = (H, Hkv, d, T, P, n_parts, n_splits, wg, dtype, use_pos, dyn)
-    assert torch.equal(k1[:, :P + T].view(torch.int16), k0[:, :P + T].view(torch.int16)), ("K rows", tag)
-    assert torch.equal(v1[:, :, :P + T].view(torch.int16), v0[:, :, :P + T].view(torch.int16)), ("V^T rows", tag)
-    assert bool(torch.isnan(k1[:, P + T:].float()).all()) and bool(torch.isnan(v1[:, :, P + T:].float()).all()), ("rows past P+T touched", tag)
-    assert torch.isfinite(out1.float()).all(), tag
-    assert torch.equal(out1.view(torch.int16), out0.view(torch.int16)), ("attention output", tag, (out1.float() - out0.float()).abs().max().item())
+
+    def same(k1, v1, out1, what):
+        assert torch.equal(k1[:, :P + T].view(torch.int16), k0[:, :P + T].view(torch.int16)), ("K rows", what, tag)
+        assert torch.equal(v1[:, :, :P + T].view(torch.int16), v0[:, :, :P + T].view(torch.int16)), ("V^T rows", what, tag)
+        assert bool(torch.isnan(k1[:, P + T:].float()).all()) and bool(torch.isnan(v1[:, :, P + T:].float()).all()), ("rows past P+T touched", what, tag)
+        assert torch.isfinite(out1.float()).all(), (what, tag)
+        assert torch.equal(out1.view(torch.int16), out0.view(torch.int16)), ("attention output", what, tag, (out1.float() - out0.float()).abs().max().item())
+
+    same(k1, v1, out1, "every split rebuilds q")
+    if n_splits > 1:
+        # ---- one launch, producer mode: dedicated work-groups do the RoPE + append once per KV head and hand it over inside the launch; three
+        # launches in a row on ONE flag buffer (lade_attn_combine leaves it zero again), the q buffer poisoned before each
+        flags = torch.zeros(64, dtype=torch.int32, device="cuda")
+        for rep in range(3):
+            k2, v2 = kc.clone(), vt.clone()
+            q2 = torch.full((T, H * d), float("nan"), dtype=dtype, device="cuda")
+            out2 = ops.attn_fwd(q2, k2, v2, m, H=H, Hkv=Hkv, d=d, n_splits=n_splits, dyn_P=dyn_P, wg_rows=wg, qkv_parts=parts, n_parts=n_parts,
+                                positions=rpos, cos=rcos, sin=rsin, sync_flags=flags)
+            torch.cuda.synchronize()
+            assert torch.equal(q2.view(torch.int16), q0.view(torch.int16)), ("q rows", "producer mode", rep, tag)
+            same(k2, v2, out2, f"producer mode, launch {rep}")
+            assert int(flags.abs().sum().item()) == 0, ("flags not reset", rep, tag)
     return out1
 
 
@@ -164,7 +181,7 @@ def test_engine_step_with_and_without_the_fused_launch_bit_identical(monkeypatch
     prompt = [rng.randrange(3, cfg["vocab"]) for _ in range(150)]
     outs = {}
     fused_calls = []
-    for fuse in (0, 1):
+    for fuse in (0, 1, 2):                                    # two launches | every split rebuilds q | producer work-groups + in-launch hand-off
         eng = StepEngine(cfg, w, dtype=torch.bfloat16, device="cuda", max_seq=512, max_T=128)
         eng.attn_default = (fuse, 128, 0)
         for graph in (False, True):
@@ -172,15 +189,16 @@ def test_engine_step_with_and_without_the_fused_launch_bit_identical(monkeypatch
             o = dec.greedy(prompt, len(prompt) + 24, rng=random.Random(1))
             n_keep = len(o.tokens) - 1                        # rows of accepted tokens: identical whatever speculative rows lie behind them
             outs[(fuse, graph)] = (o.tokens, o.steps, eng.kv.view(eng.L, 2, -1).clone(), n_keep)
-        fused_calls.append(eng.attn_cfg.get(64, eng.attn_default)[0] and eng.gemm_cfg[("wqkv", 64)] is not None and eng.gemm_cfg[("wqkv", 64)][2] <= 4)
+        fused_calls.append(bool(eng.attn_cfg.get(64, eng.attn_default)[0] and eng.gemm_cfg[("wqkv", 64)] is not None and eng.gemm_cfg[("wqkv", 64)][2] <= 4))
         del eng
-    assert fused_calls == [0, True], fused_calls              # the second engine really ran the fused launch
+    assert fused_calls == [False, True, True], fused_calls    # the second and third engines really ran the fused launch
     ref = outs[(0, False)]
     for key, (tok, steps, kv, n_keep) in outs.items():
         assert tok == ref[0] and steps == ref[1], key
     Hkv, d, S = cfg["kv_heads"], cfg["head_dim"], 512
     for graph in (False, True):
-        a, b = outs[(0, graph)], outs[(1, graph)]
-        ka, kb = a[2][:, 0].view(-1, Hkv, S, d)[:, :, :a[3]], b[2][:, 0].view(-1, Hkv, S, d)[:, :, :a[3]]
-        va, vb = a[2][:, 1].view(-1, Hkv, d, S)[:, :, :, :a[3]], b[2][:, 1].view(-1, Hkv, d, S)[:, :, :, :a[3]]
-        assert torch.equal(ka.view(torch.int16), kb.view(torch.int16)) and torch.equal(va.contiguous().view(torch.int16), vb.contiguous().view(torch.int16)), graph
+        for fuse in (1, 2):
+            a, b = outs[(0, graph)], outs[(fuse, graph)]
+            ka, kb = a[2][:, 0].view(-1, Hkv, S, d)[:, :, :a[3]], b[2][:, 0].view(-1, Hkv, S, d)[:, :, :a[3]]
+            va, vb = a[2][:, 1].view(-1, Hkv, d, S)[:, :, :, :a[3]], b[2][:, 1].view(-1, Hkv, d, S)[:, :, :, :a[3]]
+            assert torch.equal(ka.view(torch.int16), kb.view(torch.int16)) and torch.equal(va.contiguous().view(torch.int16), vb.contiguous().view(torch.int16)), (graph, fuse)
