@@ -169,8 +169,11 @@ def test_fused_rope_argument_validation():
 
 def test_engine_step_with_and_without_the_fused_launch_bit_identical(monkeypatch):
     """whole bf16 decoding runs at the 7B width (2 layers, attention and MLP live): token ids, step counts and the K / V rows with RoPE
-    fused into the attention launch == with the RoPE launch of its own, eager and hipGraph (the in-step tuner is off so that both engines
-    run the same GEMM table and only the attention launch differs)"""
+    fused into the attention launch - both forms - == with the RoPE launch of its own, eager and hipGraph.  ONE engine, the form switched
+    between runs (the in-step tuner is off, so the GEMM table is the same throughout and only the attention launch differs), after one
+    throw-away run: the first forward of a process may round a handful of projection outputs differently from every later one (library /
+    first-use effects upstream of these kernels: seen as 5 prompt rows of one layer's K differing between the first engine of a pytest
+    process and all later ones, fused or not), which is not what this test is about."""
     from lookaheaddecoding_amd.decoding import LookaheadDecoder
     from lookaheaddecoding_amd.engine import StepEngine
     from lookaheaddecoding_amd.weights import make_config, random_weights_torch
@@ -179,26 +182,30 @@ def test_engine_step_with_and_without_the_fused_launch_bit_identical(monkeypatch
     w = random_weights_torch(cfg, seed=2, dtype=torch.bfloat16, device="cuda", std=0.03)
     rng = random.Random(5)
     prompt = [rng.randrange(3, cfg["vocab"]) for _ in range(150)]
+    eng = StepEngine(cfg, w, dtype=torch.bfloat16, device="cuda", max_seq=512, max_T=128)
+    LookaheadDecoder(eng, 15, 5, 15).greedy(prompt, len(prompt) + 8, rng=random.Random(1))          # throw-away
     outs = {}
-    fused_calls = []
-    for fuse in (0, 1, 2):                                    # two launches | every split rebuilds q | producer work-groups + in-launch hand-off
-        eng = StepEngine(cfg, w, dtype=torch.bfloat16, device="cuda", max_seq=512, max_T=128)
+    for fuse in (0, 1, 2, 0):                                 # two launches | every split rebuilds q | producer work-groups + in-launch hand-off | again
         eng.attn_default = (fuse, 128, 0)
+        assert not eng.attn_cfg                               # (no tuned entry overrides the default)
         for graph in (False, True):
             dec = LookaheadDecoder(eng, 15, 5, 15, use_graph=graph)
             o = dec.greedy(prompt, len(prompt) + 24, rng=random.Random(1))
             n_keep = len(o.tokens) - 1                        # rows of accepted tokens: identical whatever speculative rows lie behind them
-            outs[(fuse, graph)] = (o.tokens, o.steps, eng.kv.view(eng.L, 2, -1).clone(), n_keep)
-        fused_calls.append(bool(eng.attn_cfg.get(64, eng.attn_default)[0] and eng.gemm_cfg[("wqkv", 64)] is not None and eng.gemm_cfg[("wqkv", 64)][2] <= 4))
-        del eng
-    assert fused_calls == [False, True, True], fused_calls    # the second and third engines really ran the fused launch
-    ref = outs[(0, False)]
+            outs[(fuse, graph, len([k for k in outs if k[:2] == (fuse, graph)]))] = (o.tokens, o.steps, eng.kv.view(eng.L, 2, -1).clone(), n_keep)
+        qkv = eng.gemm_cfg[("wqkv", 64)]
+        assert qkv is not None and qkv[2] <= 4                # the fused forms really ran (a split-K qkv GEMM with <= 4 partials)
+    ref = outs[(0, False, 0)]
+    Hkv, d, S = cfg["kv_heads"], cfg["head_dim"], 512
+    bad = []
     for key, (tok, steps, kv, n_keep) in outs.items():
         assert tok == ref[0] and steps == ref[1], key
-    Hkv, d, S = cfg["kv_heads"], cfg["head_dim"], 512
-    for graph in (False, True):
-        for fuse in (1, 2):
-            a, b = outs[(0, graph)], outs[(fuse, graph)]
-            ka, kb = a[2][:, 0].view(-1, Hkv, S, d)[:, :, :a[3]], b[2][:, 0].view(-1, Hkv, S, d)[:, :, :a[3]]
-            va, vb = a[2][:, 1].view(-1, Hkv, d, S)[:, :, :, :a[3]], b[2][:, 1].view(-1, Hkv, d, S)[:, :, :, :a[3]]
-            assert torch.equal(ka.view(torch.int16), kb.view(torch.int16)) and torch.equal(va.contiguous().view(torch.int16), vb.contiguous().view(torch.int16)), (graph, fuse)
+        a = outs[(0, key[1], 0)]
+        ka, kb = a[2][:, 0].view(-1, Hkv, S, d)[:, :, :a[3]], kv[:, 0].view(-1, Hkv, S, d)[:, :, :a[3]]
+        va, vb = a[2][:, 1].view(-1, Hkv, d, S)[:, :, :, :a[3]], kv[:, 1].view(-1, Hkv, d, S)[:, :, :, :a[3]]
+        dk = (ka.view(torch.int16) != kb.view(torch.int16)).nonzero()
+        dv = (va.contiguous().view(torch.int16) != vb.contiguous().view(torch.int16)).nonzero()
+        if len(dk) or len(dv):
+            bad.append((key, "K rows", sorted(set(dk[:, 2].tolist()))[:10], "layers", sorted(set(dk[:, 0].tolist())), "V columns", sorted(set(dv[:, 3].tolist()))[:10],
+                        "layers", sorted(set(dv[:, 0].tolist())), "n_keep", a[3], n_keep))
+    assert not bad, bad
