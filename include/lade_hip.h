@@ -155,7 +155,7 @@ typedef struct lade_attn_args {
     const void* sin_tab;
     int32_t max_pos;
     /* Producer mode of the fused form (non-null; needs n_splits > 1 and `q`): instead of every KV split rebuilding its head's q rows, the
-     * first work-groups of the grid do the RoPE + append work ONCE per (KV head, 64-key block) - rotated q rows to `q`, K / V rows to the
+     * first work-groups of the grid do the RoPE + append work ONCE per (KV head, 32 tokens) - rotated q rows to `q`, K / V rows to the
      * caches, write-through - and raise sync_flags[kvh]; the attention work-groups of that head request the cache tiles that hold no new
      * row, poll the flag from one lane (bounded: a launch never hangs) and then fetch q and the other tiles.  sync_flags: device
      * int32[Hkv], zero before the first launch; lade_attn_combine (which must follow) zeroes it again. */

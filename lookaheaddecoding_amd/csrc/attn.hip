@@ -63,7 +63,7 @@ struct AttnK {
     uint16_t* vt_w;
     int n_parts, max_pos, row_w;
     // producer mode of the fused form (sync_flags given): the first n_prod work-groups of the grid do lade_rope_kv_append_parts' work ONCE per KV head
-    // (one 64-key block each) and raise flags[kvh]; the attention work-groups of that head request the cache tiles that hold no new row, then wait for the flag
+    // (32 tokens each) and raise flags[kvh]; the attention work-groups of that head request the cache tiles that hold no new row, then wait for the flag
     int32_t* flags;
     int n_prod, prod_chunks;
 };
@@ -351,7 +351,7 @@ __device__ __forceinline__ void rope_apply(const RopeItem<NPC>& it, int n_parts,
 // ---- producer mode of the fused form ---------------------------------------------------------------------------------------------------
 // The first form above makes every KV split of a head rebuild the head's q rows from fp32 partials (+15.6 MB into the start-of-launch
 // burst: measured +3.7 us per layer).  Here lade_rope_kv_append_parts' work is done ONCE - by dedicated work-groups at the head of the
-// grid, one per (KV head, 64-key block) - and handed to the attention work-groups of that head INSIDE the launch: the producer writes the
+// grid, one per (KV head, 32 tokens) - and handed to the attention work-groups of that head INSIDE the launch: the producer writes the
 // rotated q rows (to the caller's q buffer), the K rows and the V^T columns with WRITE-THROUGH stores (sc0 sc1: the bytes leave the XCD's
 // L2 as they are issued), drains them (s_waitcnt vmcnt(0) - inline asm, so that the compiler cannot drop it), and bumps flags[kvh]
 // (relaxed, device scope).  A consumer polls the flag from ONE lane (relaxed sc1 loads, s_sleep between them, bounded), passes a
@@ -364,46 +364,22 @@ __device__ __forceinline__ void rope_apply(const RopeItem<NPC>& it, int n_parts,
 __device__ __forceinline__ void store_wt_b128(void* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void store_wt_b16(void* p, uint32_t v) { asm volatile("global_store_short %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
 
-constexpr int PROD_TOK = 64;           // keys per producer work-group: producer c of a KV head owns the keys of the 64-aligned block floor(P / 64) + c (a 60-row step: at most two per head - 64 producers + 192 attention work-groups fill the 256 CUs exactly)
-
-// producer work-groups a launch of T new tokens needs per KV head (the first and the last 64-key block may be partial)
-__host__ __device__ __forceinline__ int prod_blocks_max(int T) { return (T + PROD_TOK - 1) / PROD_TOK + 1; }
-// ... and how many of them really own a key at cache length P (what a consumer waits for)
-__device__ __forceinline__ int prod_blocks(int P, int T) { return (P + T + PROD_TOK - 1) / PROD_TOK - P / PROD_TOK; }
+constexpr int PROD_TOK = 32;           // tokens per producer work-group
 
 template <typename T, int D, int NPC, int NTHR>
 __device__ __forceinline__ void rope_producer(const AttnK& a, unsigned char* smem) {
     constexpr int VPH = D / 16, LDV = D + 2;
-    constexpr int VS = (PROD_TOK * (D / 4) + NTHR - 1) / NTHR;           // float4 sites of the block's V rows per thread
     const int tid = threadIdx.x;
     const int pb = blockIdx.x;
     const int kvh = pb / a.prod_chunks, ch = pb - kvh * a.prod_chunks;
     if (kvh >= a.Hkv) return;                                   // padding of the producer range to a multiple of 8
     int P = a.m.P;
     if (a.dyn_P) P = *a.dyn_P;
-    // keys [k_lo, k_hi) of the 64-aligned block this work-group owns: 16-byte runs of V^T columns start on 8-column boundaries everywhere
-    // but at the two ends of the new rows (write-through stores of 2 bytes are one fabric write each: the first build of this mode
-    // issued 7680 of them per head and lost 1.4 us per layer to the two-launch form)
-    const int blk = P / PROD_TOK + ch;
-    const int k_lo = max(P, blk * PROD_TOK), k_hi = min(P + a.m.T, (blk + 1) * PROD_TOK);
-    if (k_lo >= k_hi) return;                                   // (not counted: consumers wait for prod_blocks(P, T) arrivals)
-    const int t0 = k_lo - P, nt_ = k_hi - k_lo;
+    const int t0 = ch * PROD_TOK, nt_ = min(PROD_TOK, a.m.T - t0);
     const int n_rep = a.n_rep;
     const bool writes = P + a.m.T <= a.S_max;                   // (a device-side cache length past the cache: nothing is written, as in lade_rope_kv_append)
     uint16_t* q_out = const_cast<uint16_t*>(a.q);
     if (writes) {
-        // every load of the V rows is requested before the rope items are worked through (one memory latency for both)
-        const size_t v_col = (size_t)(a.H + a.Hkv + kvh) * D;
-        float4 vp[VS][NPC];
-#pragma unroll
-        for (int sv = 0; sv < VS; ++sv) {
-            const int idx = tid + sv * NTHR, tt = idx / (D / 4), d4 = (idx - tt * (D / 4)) * 4;
-            if (idx < PROD_TOK * (D / 4) && tt < nt_) {
-                const size_t e0 = (size_t)(t0 + tt) * a.row_w + v_col + d4;
-#pragma unroll
-                for (int j = 0; j < NPC; ++j) vp[sv][j] = *reinterpret_cast<const float4*>(a.parts + (size_t)min(j, a.n_parts - 1) * a.part_stride + e0);
-            }
-        }
         // q rows of the group's heads + the K row: one item = 8 + 8 values (columns i.., i + D/2..) of one head row
         const int per_tok = (n_rep + 1) * VPH;
         for (int idx = tid; idx < nt_ * per_tok; idx += NTHR) {
@@ -423,39 +399,26 @@ __device__ __forceinline__ void rope_producer(const AttnK& a, unsigned char* sme
         }
         // V rows: partials summed in split order, rounded once, transposed through LDS ([token][d], padded rows)
         uint16_t* stage_v = reinterpret_cast<uint16_t*>(smem);
+        const size_t v_col = (size_t)(a.H + a.Hkv + kvh) * D;
+        for (int idx = tid; idx < nt_ * (D / 4); idx += NTHR) {
+            const int tt = idx / (D / 4), d4 = (idx - tt * (D / 4)) * 4;
+            const size_t e0 = (size_t)(t0 + tt) * a.row_w + v_col + d4;
+            float4 vp[NPC];
 #pragma unroll
-        for (int sv = 0; sv < VS; ++sv) {
-            const int idx = tid + sv * NTHR, tt = idx / (D / 4), d4 = (idx - tt * (D / 4)) * 4;
-            if (idx < PROD_TOK * (D / 4) && tt < nt_) {
-                float4 acc = float4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NPC; ++j) vp[j] = *reinterpret_cast<const float4*>(a.parts + (size_t)min(j, a.n_parts - 1) * a.part_stride + e0);
+            float4 acc = float4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < NPC; ++j)
-                    if (j < a.n_parts) { acc.x += vp[sv][j].x; acc.y += vp[sv][j].y; acc.z += vp[sv][j].z; acc.w += vp[sv][j].w; }
-                uint32_t* dst = reinterpret_cast<uint32_t*>(stage_v + tt * LDV + d4);
-                dst[0] = (uint32_t)from_f32<T>(acc.x) | ((uint32_t)from_f32<T>(acc.y) << 16);
-                dst[1] = (uint32_t)from_f32<T>(acc.z) | ((uint32_t)from_f32<T>(acc.w) << 16);
-            }
+            for (int j = 0; j < NPC; ++j)
+                if (j < a.n_parts) { acc.x += vp[j].x; acc.y += vp[j].y; acc.z += vp[j].z; acc.w += vp[j].w; }
+            uint32_t* dst = reinterpret_cast<uint32_t*>(stage_v + tt * LDV + d4);
+            dst[0] = (uint32_t)from_f32<T>(acc.x) | ((uint32_t)from_f32<T>(acc.y) << 16);
+            dst[1] = (uint32_t)from_f32<T>(acc.z) | ((uint32_t)from_f32<T>(acc.w) << 16);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         wg_barrier();
-        // V^T[d][k_lo .. k_hi): per d row the 8-column groups of the block - a whole group inside the run is ONE 16-byte write-through store,
-        // a group cut by the run's start (P) or end (P + T) is written column by column
-        constexpr int GRP = PROD_TOK / 8;
-        for (int idx = tid; idx < D * GRP; idx += NTHR) {
-            const int dd = idx / GRP, gidx = idx - dd * GRP;
-            const int c0 = blk * PROD_TOK + gidx * 8;                        // first column of the group (8-aligned: 16-byte aligned in V^T)
-            if (c0 + 8 <= k_lo || c0 >= k_hi) continue;
-            uint16_t* dst = a.vt_w + ((size_t)kvh * D + dd) * a.S_max + c0;
-            if (c0 >= k_lo && c0 + 8 <= k_hi) {
-                u32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    v[e] = (uint32_t)stage_v[(c0 - k_lo + 2 * e) * LDV + dd] | ((uint32_t)stage_v[(c0 - k_lo + 2 * e + 1) * LDV + dd] << 16);
-                store_wt_b128(dst, v);
-            } else {
-                for (int e = 0; e < 8; ++e)
-                    if (c0 + e >= k_lo && c0 + e < k_hi) store_wt_b16(dst + e, stage_v[(c0 + e - k_lo) * LDV + dd]);
-            }
+        for (int idx = tid; idx < D * PROD_TOK; idx += NTHR) {
+            const int dd = idx / PROD_TOK, tt = idx - dd * PROD_TOK;
+            if (tt < nt_) store_wt_b16(a.vt_w + ((size_t)kvh * D + dd) * a.S_max + P + t0 + tt, stage_v[tt * LDV + dd]);
         }
     }
     // every store of this wave has left the chip's caches; then the barrier; then ONE arrival per work-group
@@ -679,8 +642,7 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
             }
             if (tid == 0) {                          // ONE lane polls (relaxed, device scope: an sc1 load), bounded: ~0.1 s, then the launch ends wrong rather than never
                 int spins = 0;
-                const int want = prod_blocks(m.P, m.T);
-                while (__hip_atomic_load(a.flags + kvh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(2);
+                while (__hip_atomic_load(a.flags + kvh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.prod_chunks && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(2);
             }
             wg_barrier();
             sc1_from_q = first_new_q;                // from here on the tiles that hold new rows are requested with sc1 loads
@@ -1234,7 +1196,7 @@ static AttnK make_k(const lade_attn_args* a) {
     k.k_w = (uint16_t*)a->k_cache; k.vt_w = (uint16_t*)a->vt_cache;
     k.n_parts = a->n_parts; k.max_pos = a->max_pos; k.row_w = (a->H + 2 * a->Hkv) * a->d;
     k.flags = a->n_parts ? a->sync_flags : nullptr;
-    k.prod_chunks = prod_blocks_max(a->mask.T);
+    k.prod_chunks = cdiv(a->mask.T, PROD_TOK);
     k.n_prod = k.flags ? 8 * cdiv(a->Hkv * k.prod_chunks, 8) : 0;
     return k;
 }
