@@ -170,26 +170,24 @@ def test_fused_rope_argument_validation():
 def test_engine_step_with_and_without_the_fused_launch_bit_identical(monkeypatch):
     """whole bf16 decoding runs at the 7B width (2 layers, attention and MLP live): token ids, step counts and the K / V rows with RoPE
     fused into the attention launch - both forms - == with the RoPE launch of its own, eager and hipGraph.  ONE engine, the form switched
-    between runs (the in-step tuner is off, so the GEMM table is the same throughout and only the attention launch differs).  The engine
-    holds its weights K-tile-major ONLY, so that no projection of a <= 256-row step can fall to the library GEMM: hipBLASLt's stream-K
-    kernels sum in a run-dependent order, and a prefill chunk that takes one (the 128-row class, where the tuner sometimes prefers it)
-    flips a handful of K rows by one bf16 spacing from run to run - seen here as 5 prompt rows of one layer differing between otherwise
-    identical runs, fused or not - which is not what this test is about."""
+    between runs (the in-step tuner is off, so the GEMM table is the same throughout and only the attention launch differs).  Every form
+    runs 64-row work-groups: a fused launch fed by 3 or 4 partials cannot take the 128-row shape (registers, attn.hip launch_fwd_npc), and the
+    isolated GEMM tuner does sometimes pick 4 splits for the 128-row qkv class - the 128- and 64-row shapes merge their key parts in a
+    different order and differ by one bf16 spacing in a handful of rows (seen as 5 prompt rows of a layer's K / V, in the runs where the tuner
+    had picked 4 splits: tools/fused_rope_diag.py)."""
     from lookaheaddecoding_amd.decoding import LookaheadDecoder
     from lookaheaddecoding_amd.engine import StepEngine
     from lookaheaddecoding_amd.weights import make_config, random_weights_torch
     monkeypatch.setenv("LADE_TUNE_STEP", "0")
-    monkeypatch.setenv("LADE_W_KTILE", "only")
     cfg = make_config("llama2-7b", layers=2)
     w = random_weights_torch(cfg, seed=2, dtype=torch.bfloat16, device="cuda", std=0.03)
     rng = random.Random(5)
     prompt = [rng.randrange(3, cfg["vocab"]) for _ in range(150)]
-    eng = StepEngine(cfg, w, dtype=torch.bfloat16, device="cuda", max_seq=512, max_T=128, consume_weights=True)
-    assert eng.ktile_only
+    eng = StepEngine(cfg, w, dtype=torch.bfloat16, device="cuda", max_seq=512, max_T=128)
     LookaheadDecoder(eng, 15, 5, 15).greedy(prompt, len(prompt) + 8, rng=random.Random(1))          # throw-away
     outs = {}
     for fuse in (0, 1, 2, 0):                                 # two launches | every split rebuilds q | producer work-groups + in-launch hand-off | again
-        eng.attn_default = (fuse, 128, 0)
+        eng.attn_default = (fuse, 64, 0)
         assert not eng.attn_cfg                               # (no tuned entry overrides the default)
         for graph in (False, True):
             dec = LookaheadDecoder(eng, 15, 5, 15, use_graph=graph)
@@ -198,7 +196,6 @@ def test_engine_step_with_and_without_the_fused_launch_bit_identical(monkeypatch
             outs[(fuse, graph, len([k for k in outs if k[:2] == (fuse, graph)]))] = (o.tokens, o.steps, eng.kv.view(eng.L, 2, -1).clone(), n_keep)
         qkv = eng.gemm_cfg[("wqkv", 64)]
         assert qkv is not None and qkv[2] <= 4                # the fused forms really ran (a split-K qkv GEMM with <= 4 partials)
-    assert all(c is not None for (n, _m), c in eng.gemm_cfg.items() if n != "lm_head"), eng.gemm_cfg        # no layer projection on the library
     ref = outs[(0, False, 0)]
     Hkv, d, S = cfg["kv_heads"], cfg["head_dim"], 512
     bad = []
