@@ -379,7 +379,7 @@ int lade_gather_rows(const void* src, const int32_t* idx, void* dst, int32_t row
  * C[M,N] = A[M,K] . W[N,K]^T for the projections of a decode step (M = T <= ~256 rows), bf16 / f16, fp32 accumulate.
  * n_split == 1: writes C (model dtype).  n_split > 1: writes fp32 partials Cpart[n_split][M][N] (summed in split
  * order - deterministic - by lade_splitk_reduce).  bn = weight rows per work-group (32..256), mb = 32-row activation
- * blocks per work-group (1: 32 rows, 2: 64, 3: 96, 4: 128, 5: 160, 6: 192, 7: 224, 8: 256, 0: by M; larger M runs as several row blocks).  mt = 32-row activation blocks per WAVE (0 | 1..7, divides
+ * blocks per work-group (1: 32 rows, 2: 64, 3: 96, 4: 128, 0: by M; larger M runs as several row blocks).  mt = 32-row activation blocks per WAVE (0 | 1..4, divides
  * mb) and nt = 32-row weight tiles per wave (0 = fewest): the waves form an (mb/mt) x (bn/32/nt) grid; larger wave tiles
  * re-read less from LDS per weight byte.  ring = stages of the LDS ring the tiles arrive in (0 = default: 4 where they fit; 2, 3, 4, 5, 6, 8): a
  * deeper ring keeps more bytes in flight per work-group and leaves room for fewer co-resident work-groups - chosen per projection by the

@@ -71,10 +71,10 @@ static int gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, b
                  "lade_gemm_skinny: K=%d must be a multiple of %d, strides / N multiples of 8", K, G_BK);
     LADE_REQUIRE(epilogue == 2 || (n_split == 1 ? (C != nullptr && ldc % (epilogue ? 4 : 8) == 0) : (Cpart != nullptr)), LADE_E_ARG, "lade_gemm_skinny: missing output buffer");
     LADE_REQUIRE(dtype == LADE_BF16 || dtype == LADE_F16, LADE_E_DTYPE, "lade_gemm_skinny: dtype=%d", dtype);
-    if (mb == 0) mb = M <= 32 ? 1 : (M <= 64 ? 2 : (M <= 96 ? 3 : (M <= 128 ? 4 : (M <= 160 ? 5 : (M <= 192 ? 6 : (M <= 224 ? 7 : 8))))));
-    if (mt == 0) mt = mb <= 4 ? 1 : (mb % 2 ? mb : mb / 2);              // (5 / 7 blocks: one m-group whose waves own all of them)
+    if (mb == 0) mb = M <= 32 ? 1 : (M <= 64 ? 2 : (M <= 96 ? 3 : (M <= 128 ? 4 : (M <= 192 ? 6 : 8))));
+    if (mt == 0) mt = mb <= 4 ? 1 : mb / 2;
     if (mb > 4 && nt == 0) nt = 1;
-    LADE_REQUIRE(mb >= 1 && mb <= 8 && mt >= 1 && mt <= 7 && mb % mt == 0, LADE_E_ARG, "lade_gemm_skinny: mb=%d mt=%d", mb, mt);
+    LADE_REQUIRE(mb >= 1 && mb <= 8 && mt >= 1 && mt <= 4 && mb % mt == 0, LADE_E_ARG, "lade_gemm_skinny: mb=%d mt=%d", mb, mt);
     // 192 / 256-row work-groups: the activation tile leaves room for <= 128 weight rows per stage of a 3-stage ring; the one wider
     // shape is the double-buffered 256 x 256 tile (mb = 8, bn = 256, nt = 2 | 4)
     if (mb > 4 && bn > 128 && !(mb == 8 && bn == 256 && (nt == 2 || nt == 4))) {

@@ -389,9 +389,6 @@ static int launch_gemm(const GemmK& g0, hipStream_t st) {
                    SHAPE(TT,1,4,4,1) SHAPE(TT,1,4,6,1) SHAPE(TT,1,4,8,1) SHAPE(TT,1,4,3,2) SHAPE(TT,1,4,4,2) SHAPE(TT,1,4,2,2)                    \
     /* 224-row weight blocks (N = 57344 = 256 x 224: Llama-2-70B gate/up on 256 CUs in one wave of work-groups) */        \
                    SHAPE(TT,1,1,7,1) SHAPE(TT,1,2,7,1) SHAPE(TT,1,3,7,1) SHAPE(TT,1,4,7,1)                                      \
-    /* 160 rows (round 5: a 132-row step - config 4 with two candidates - no longer pads to 192) */                       \
-                   SHAPE(TT,1,5,2,1) SHAPE(TT,1,5,3,1) SHAPE(TT,1,5,4,1) SHAPE(TT,5,1,1,2) SHAPE(TT,5,1,1,4)                                      \
-    /* 224 rows */ SHAPE(TT,1,7,2,1) SHAPE(TT,1,7,3,1) SHAPE(TT,1,7,4,1) SHAPE(TT,7,1,1,2) SHAPE(TT,7,1,1,4)                                      \
     /* 192 rows */ SHAPE(TT,2,3,2,1) SHAPE(TT,2,3,4,1) SHAPE(TT,2,3,2,2) SHAPE(TT,3,2,2,1) SHAPE(TT,3,2,2,2)                                     \
     /* 256 rows */ SHAPE(TT,2,4,2,1) SHAPE(TT,2,4,4,1) SHAPE(TT,2,4,2,2) SHAPE(TT,4,2,2,1) SHAPE(TT,4,2,2,2)                                     \
     /* 256 x 256 compute-shaped tile (steps and prefill chunks wider than 256 rows run as several row blocks): 4 x 2 / 2 x 4 MFMA tiles  \

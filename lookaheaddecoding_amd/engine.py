@@ -101,7 +101,7 @@ _TUNE_RANKED: dict = {}
 _TUNE_LOCK = __import__("threading").Lock()
 _STEP_TUNE_CACHE: dict = {}
 _STEP_TUNE_LOCK = __import__("threading").Lock()
-REP_ROWS = {32: 30, 64: 60, 96: 92, 128: 128, 160: 150, 192: 180, 224: 210, 256: 240}        # the rows a row class is timed at
+REP_ROWS = {32: 30, 64: 60, 96: 92, 128: 128, 192: 180, 256: 240}        # the rows a row class is timed at
 
 
 class StepEngine:
@@ -174,8 +174,6 @@ class StepEngine:
         # the default until (unless) the in-step pass decides: RoPE + append as a launch of their own (the fused form measured +3.7 us per
         # layer at the 7B step - every split re-reads the q rows as fp32 partials; LADE_FUSE_ROPE=1 makes it the default, the
         # in-step pass always tries both), the 128-row shape, the sqrt split rule
-        if os.environ.get("LADE_ROW_CLASSES") == "r4":          # A/B switch: the row classes of rounds 1-4 (no 160 / 224)
-            self.ROW_CLASSES = (32, 64, 96, 128, 192, 256)
         self.attn_cfg = {}
         self.attn_default = (int(os.environ.get("LADE_FUSE_ROPE", "0")) if os.environ.get("LADE_FUSE_ROPE", "0") in ("1", "2") else 0, 128, 0)
         self.step_tune_log = {}             # row class -> what the in-step pass measured (bench.py prints it)
@@ -485,9 +483,7 @@ class StepEngine:
                         (4, 2, 1, (96,))),
                   # 192 / 256 rows (config 4's 120 + 6g-token steps, hot-regime steps): the activation tile alone is 24 / 32 KB per stage,
                   # so the weight tile stays at <= 128 rows for the 3-stage ring to fit the 160 KB of LDS
-                  160: ((5, 5, 1, (64, 96, 128)), (5, 1, 2, (64,)), (5, 1, 4, (128,))),
                   192: ((6, 3, 1, (64, 128)), (6, 3, 2, (128,)), (6, 2, 1, (64,)), (6, 2, 2, (128,))),
-                  224: ((7, 7, 1, (64, 96, 128)), (7, 1, 2, (64,)), (7, 1, 4, (128,))),
                   256: ((8, 4, 1, (64, 128)), (8, 4, 2, (128,)), (8, 2, 1, (64,)), (8, 2, 2, (128,)))}[mclass]
         for mb, mt, nt, bns in shapes:
             for bn in bns:
@@ -533,9 +529,9 @@ class StepEngine:
             # no split-K: BN weight rows x the whole K per work-group, SwiGLU in the epilogue, output in the model dtype.  Needs
             # N / BN work-groups to cover the CUs on their own: 96-row blocks at the 7B / 13B widths.
             act = torch.empty(a.shape[0], N // 2, dtype=self.dtype, device=self.device)
-            mbs = {32: 1, 64: 2, 96: 3, 128: 4, 160: 5, 192: 6, 224: 7, 256: 8}[mclass]
+            mbs = {32: 1, 64: 2, 96: 3, 128: 4, 192: 6, 256: 8}[mclass]
             for bn in (64, 96, 128) + ((224,) if N % 224 == 0 else ()):        # 224: N = 256 x 224 at the 70B width
-                for mt in sorted({1, 2 if mbs % 2 == 0 else 1, mbs if (mbs <= 4 or mbs % 2) else mbs // 2}):
+                for mt in sorted({1, 2 if mbs % 2 == 0 else 1, mbs if mbs <= 4 else mbs // 2}):
                     if mbs % mt or (mbs // mt) * (bn // 32) > 8:
                         continue
                     try:
@@ -577,7 +573,7 @@ class StepEngine:
         N / bn work-groups cover the CUs on their own at vocabulary sizes, the output is written once in the model dtype - against
         the library.  Measured at V = 32000, K = 4096, 16 rows: library 57.3 us, skinny on row-major weights 48.3 us, on the K-tile-major
         copy 39.4 us (6.65 TB/s; `profiles/r3_lm_head_probe.txt`)."""
-        mbs = {32: 1, 64: 2, 96: 3, 128: 4, 160: 5, 192: 6, 224: 7, 256: 8}[mclass]
+        mbs = {32: 1, 64: 2, 96: 3, 128: 4, 192: 6, 256: 8}[mclass]
 
         def time_it(fn, reps=12):
             best_t = float("inf")
@@ -596,7 +592,7 @@ class StepEngine:
         t_lib = time_it(lambda: torch.matmul(a, ws_lib[0].t(), out=out))
         timed = []
         for bn in (64, 96, 128, 192, 256):
-            for mt in sorted({1, mbs if (mbs <= 4 or mbs % 2) else mbs // 2}):
+            for mt in sorted({1, mbs if mbs <= 4 else mbs // 2}):
                 for nt in (0, 1, 2):
                     if mbs % mt:
                         continue
@@ -845,7 +841,7 @@ class StepEngine:
 
     LAYER_GEMMS = ("wqkv", "wo", "wgu", "wd")
     GEMM_NAMES = LAYER_GEMMS + ("lm_head",)
-    ROW_CLASSES = (32, 64, 96, 128, 160, 192, 224, 256)       # (160 / 224: round 5 - a 132-row step no longer pads to 192, a 198-row one not to 256)
+    ROW_CLASSES = (32, 64, 96, 128, 192, 256)
 
     TUNE_NAMES = GEMM_NAMES + ("attn",)        # rows of the decision table lookahead-parallel ranks exchange (parallel.encode_tune_table)
 

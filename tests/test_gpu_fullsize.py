@@ -124,7 +124,7 @@ def test_skinny_gemm_vs_fp32_reference():
     from lookaheaddecoding_amd import ops
     torch.manual_seed(4)
     for (M, N, K) in ((60, 4096, 4096), (120, 12288, 4096), (76, 4096, 11008), (1, 512, 128), (37, 264, 192), (16, 2048, 2048), (31, 4096, 4096),
-                      (240, 5120, 5120), (150, 4096, 4096), (180, 2048, 13824), (210, 4096, 4096)):
+                      (240, 5120, 5120), (150, 4096, 4096), (180, 2048, 13824)):
         a = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
         ref = a.float() @ w.float().t()
         for (S, bn, mb, mt, nt) in [x + (0,) for x in ((1, 128, 0, 0), (4, 128, 0, 0), (3, 64, 4, 1), (2, 256, 0, 0), (2, 192, 3, 1), (5, 64, 3, 1), (1, 256, 3, 1), (3, 64, 1, 1),
@@ -135,10 +135,7 @@ def test_skinny_gemm_vs_fp32_reference():
                                     # 192 / 256-row work-groups (steps of up to 256 tokens: the weights are streamed once)
                                     (1, 224, 2, 2, 1), (2, 224, 1, 1, 1), (3, 224, 4, 4, 1),      # 7-tile weight blocks
                                     (2, 128, 8, 4, 1), (4, 64, 8, 4, 1), (1, 128, 8, 4, 2), (3, 64, 8, 2, 1), (2, 128, 8, 2, 2), (2, 128, 6, 3, 1), (3, 64, 6, 3, 1),
-                                    (2, 128, 6, 3, 2), (2, 64, 6, 2, 1), (1, 128, 6, 2, 2), (2, 128, 0, 0, 0),
-                                    # 160 / 224-row work-groups (round 5)
-                                    (2, 128, 5, 5, 1), (3, 64, 5, 1, 2), (2, 128, 5, 1, 4), (1, 96, 5, 5, 1), (2, 128, 7, 7, 1), (1, 64, 7, 7, 1), (2, 64, 7, 1, 2),
-                                    (3, 128, 7, 1, 4)]:
+                                    (2, 128, 6, 3, 2), (2, 64, 6, 2, 1), (1, 128, 6, 2, 2), (2, 128, 0, 0, 0)]:
             if K // 64 < S:
                 continue
             out = ops.gemm_skinny(a, w, n_split=S, bn=bn, mb=mb, mt=mt, nt=nt).float()
