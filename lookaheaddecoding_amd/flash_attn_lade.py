@@ -17,7 +17,7 @@ and an all-zero tuple (apart from kv_cache) is the plain causal call of a prefil
 
 K / V arrive token-major while the kernel streams K [Hkv][S_max][d] and V TRANSPOSED [Hkv][d][S_max]; `lade_kv_pack_bshd` re-lays them
 (one launch, each byte read and written once).  That costs about what the reference's own per-layer `torch.cat` of the whole cache costs
-(:626-629) - 2 x 36 MB at the BASELINE shape, ~12 us at the HBM rate - and is why the product path (`StepEngine`) binds one level higher,
+(:626-629) - 37 MB read + 37 MB written at the BASELINE shape: measured 18 us on top of the 18 us attention pair (profiles/r5_flash_boundary_bench.txt) - and is why the product path (`StepEngine`) binds one level higher,
 at the model step, where the cache stays resident in the kernel's layout.  This adapter exists so that the operator
 the reference actually calls has a drop-in and a parity test (tests/test_gpu_flash_boundary.py).
 """
