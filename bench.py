@@ -805,7 +805,7 @@ def worker(args):
             lp_default = {"W": Wd, "N": Nd, "G": Gd, "value": round((len(run_d.tokens) - tokd) / td, 2), "unit": "tokens/s", "ms_per_step": round(td / args.steps * 1e3, 3),
                           "step_compression": round((len(run_d.tokens) - tokd) / args.steps, 3), "rows_per_rank_cold": rows, "rows_one_rank_cold": (Nd - 1) * Wd,
                           "expected_speedup_vs_one_rank": {"2": 1.45, "4": 1.65, "8": 2.17},
-                          "expected_source": "profiles/r4_lp_curve_7b.txt: every rank's shard of the 7B shape timed on ONE GPU (forward + argmax, cold: 10.05 / 6.93 / 6.10 / 4.64 ms at "
+                          "expected_source": "profiles/r4_lp_curve_7b.txt (reproduced on the round-5 build: profiles/r5_lp_curve_7b.txt, 1.45 / 1.66 / 2.17): every rank's shard of the 7B shape timed on ONE GPU (forward + argmax, cold: 10.05 / 6.93 / 6.10 / 4.64 ms at "
                                              "1 / 2 / 4 / 8 ranks), + one int32 all-gather and lade_lp_reduce_apply per step (~30-40 us); the floor is the one-token weight stream",
                           "status": "no lookahead-parallel run on more than one physical GPU exists yet (one GPU per lease in rounds 1-5): compare the driver's numbers with `expected`",
                           "what": "the reference's default lookahead configuration on the same ranks, same engine, same prompt: the curve that shards"}
