@@ -353,12 +353,15 @@ static int launch_rmsnorm(void* x, const void* r, const void* weight, void* y, i
     const int nvec_bytes = dtype == LADE_F32 ? 4 : 8;
     LADE_REQUIRE(hidden % nvec_bytes == 0, LADE_E_ARG, "lade_rmsnorm: hidden=%d must be a multiple of %d", hidden, nvec_bytes);
     const int vecs = hidden / nvec_bytes;              // 16-byte chunks per row
-    LADE_REQUIRE(vecs <= 8 * 512, LADE_E_LIMIT, "lade_rmsnorm: hidden=%d too large for the register-resident row", hidden);
+    LADE_REQUIRE(vecs <= 4 * 1024, LADE_E_LIMIT, "lade_rmsnorm: hidden=%d too large for the register-resident row", hidden);
 #define RMS_LAUNCH(CH, BT) DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((rmsnorm_kernel<TT, ADD, CH, BT>), dim3(rows), dim3(BT), 0, st, (St<TT>::S*)x, \
                                           (const St<TT>::S*)r, (const St<TT>::S*)weight, (St<TT>::S*)y, hidden, eps, parts, n_parts, part_stride, sel, src_rows))
-    // one 16-byte chunk per thread up to 512 threads (every load of the row in flight at once), then 2 / 4 / 8 chunks
-    if (vecs <= 256) { RMS_LAUNCH(1, 256); } else if (vecs <= 512) { RMS_LAUNCH(1, 512); } else if (vecs <= 1024) { RMS_LAUNCH(2, 512); }
-    else if (vecs <= 2048) { RMS_LAUNCH(4, 512); } else { RMS_LAUNCH(8, 512); }
+    // one 16-byte chunk per thread up to 1024 threads - every load of the row (x, all its split-K partials, the weight) is in flight at
+    // once; with two chunks per thread the store of chunk 0 into x sits between the loads of chunk 0 and chunk 1 (x may alias them), so the
+    // row pays its memory latency twice: 8.7-12 us instead of 5.5-6.5 at hidden 5120 / 8192 (profiles/r5_bench_c4_kernel_medians.txt)
+    if (vecs <= 256) { RMS_LAUNCH(1, 256); } else if (vecs <= 512) { RMS_LAUNCH(1, 512); } else if (vecs <= 640) { RMS_LAUNCH(1, 640); }
+    else if (vecs <= 768) { RMS_LAUNCH(1, 768); } else if (vecs <= 1024) { RMS_LAUNCH(1, 1024); } else if (vecs <= 2048) { RMS_LAUNCH(2, 1024); }
+    else { RMS_LAUNCH(4, 1024); }
 #undef RMS_LAUNCH
     return check_launch(ADD ? "lade_add_rmsnorm" : "lade_rmsnorm");
 }
