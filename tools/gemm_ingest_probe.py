@@ -43,6 +43,10 @@ for name, N, K, S, bn, mt, nt, ring in cfgs:
     a = torch.randn(M, K, device="cuda").bfloat16()
     n_w = max(3, int(700e6 / (N * K * 2)))
     kts = [ops.to_ktile((torch.randn(N, K, device="cuda") * 0.02).bfloat16()) for _ in range(n_w)]
+    if os.environ.get("ZERO") == "1":         # all-zero operands: same instructions, same bytes, less switching power (the guide's DVFS give-back check)
+        a.zero_()
+        for k in kts:
+            k.zero_()
     part = torch.empty(16 * 128 * N, dtype=torch.float32, device="cuda")
     act = torch.empty(M, N // 2, dtype=torch.bfloat16, device="cuda")
     i = [0]
