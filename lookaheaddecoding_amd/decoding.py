@@ -107,6 +107,9 @@ class LadeState:
             time.sleep(0)                      # release the GIL: other threads of the process get to run
 
 
+DRAW_WITH_TORCH = os.environ.get("LADE_DRAW_TORCH") == "1"
+
+
 class LookaheadDecoder:
     """Greedy / sampling lookahead decoding of one sequence on a `StepEngine`."""
 
@@ -394,7 +397,9 @@ class LookaheadDecoder:
             self._smp = dict(scal=torch.zeros(rows * G, dtype=torch.float32, device=dev), stats=torch.zeros(rows * 2, dtype=torch.float32, device=dev),
                              scal_host=torch.zeros(rows * G, dtype=torch.float32).pin_memory(), guess_host=torch.zeros(G * gs, dtype=torch.int32).pin_memory(),
                              probs=torch.zeros(1, e.V, dtype=torch.float32, device=dev), probs_host=torch.zeros(e.V, dtype=torch.float32).pin_memory(),
-                             am_host=torch.zeros(self.W, dtype=torch.int32).pin_memory())
+                             am_host=torch.zeros(self.W, dtype=torch.int32).pin_memory(),
+                             forced_host=torch.zeros(2 + cabi.MAX_LEVEL, dtype=torch.int32).pin_memory())
+            self._smp["forced_np"] = self._smp["forced_host"].numpy()
         return self._smp
 
     def _draw(self, src: torch.Tensor, row: int, temperature: float, struck: Sequence[int], torch_gen: Optional[torch.Generator]):
@@ -402,11 +407,13 @@ class LookaheadDecoder:
         generator keeps the draw on the device (what the reference does with the model on a GPU): the token is returned as a
         device tensor and reaches the host with the step's record.  Otherwise the one row goes to the host and
         torch.multinomial consumes the CPU generator (reproducible against the CPU-generated reference traces): returns an int."""
-        from .sampling import final_distribution
+        from .sampling import final_distribution, multinomial_one
         b = self._sampling_buffers()
         probs = ops.softmax_rows(src[row:row + 1], temperature, out=b["probs"])[0]
         if torch_gen is not None and torch_gen.device.type == "cuda":
-            return torch.multinomial(final_distribution(probs, struck), num_samples=1, generator=torch_gen).to(torch.int32)
+            if DRAW_WITH_TORCH:                   # LADE_DRAW_TORCH=1: torch.multinomial itself, input checks included (the same token, 12 launches more)
+                return torch.multinomial(final_distribution(probs, struck), num_samples=1, generator=torch_gen)
+            return multinomial_one(final_distribution(probs, struck), torch_gen)
         b["probs_host"].copy_(probs, non_blocking=True)
         torch.cuda.current_stream().synchronize()
         return int(torch.multinomial(final_distribution(b["probs_host"].clone(), struck), num_samples=1, generator=torch_gen).item())
@@ -419,6 +426,15 @@ class LookaheadDecoder:
         e, W = self.e, self.W
         rng = rng if rng is not None else random
         self.start(prompt, eos_token_id, rng)
+        if torch_gen is not None and torch_gen.device.type == "cuda" and not getattr(self, "_draw_warm", False):
+            # the draw's torch kernels (exponential, divide, argmax, and the strike-and-renormalise ops of a rejected draft) load their code
+            # objects on first use: 10-26 ms in the middle of the first step that rejects a draft.  One dry run on a throw-away generator -
+            # the caller's generator is not touched
+            from .sampling import final_distribution, multinomial_one
+            tg = torch.Generator(device=e.device).manual_seed(0)
+            tok = multinomial_one(final_distribution(torch.full((e.V,), 1.0 / e.V, dtype=torch.float32, device=e.device), [0, 1]), tg)
+            torch.zeros(4, dtype=torch.int32, device=e.device)[1:2].copy_(tok)
+            self._draw_warm = True
         self._s = dict(warp=warp, fused_T=1.0 if warp is None else getattr(warp, "fused_temperature", None), rng=rng, torch_gen=torch_gen,
                        old=list(self.prompt), forced=torch.zeros(2 + cabi.MAX_LEVEL, dtype=torch.int32, device=e.device),
                        override=torch.zeros(W, dtype=torch.int32, device=e.device))
@@ -542,7 +558,10 @@ class LookaheadDecoder:
             if any(x >= 0 for x in repl):
                 override.copy_(torch.tensor(repl, dtype=torch.int32))
                 level_override = override
-        forced.copy_(torch.tensor([max_hit, max_hit_idx] + hits + [0] * (cabi.MAX_LEVEL - len(hits)), dtype=torch.int32), non_blocking=True)
+        # pinned staging (a pageable source would make the copy wait for the draw's kernels on the host); the previous step's copy is long
+        # done: every step ends with the record's stream synchronisation
+        buf["forced_np"][:] = [max_hit, max_hit_idx] + hits + [0] * (cabi.MAX_LEVEL - len(hits))
+        forced.copy_(buf["forced_host"], non_blocking=True)
         if drawn_on_device is not None:
             forced[2 + max_hit:3 + max_hit].copy_(drawn_on_device)          # the drawn token never left the device
         call("lade_greedy_post_step", ptr(st.ctl), ptr(st.window), st.wcap, ptr(st.pool_tok), ptr(st.pool_cnt), st.V, W, N, G,

@@ -107,6 +107,17 @@ def resolve_drafts(table: Sequence[Sequence[float]], drafts: Sequence[int], g: i
     return Verdict(accepted, winner, None, [])
 
 
+def multinomial_one(probs_row: torch.Tensor, generator: Optional[torch.Generator]) -> torch.Tensor:
+    """`torch.multinomial(probs_row, num_samples=1, generator=generator)` (the draw of lade/decoding.py:484-540) for a device row,
+    launch for launch what torch runs behind its input checks: q ~ Exp(1) from the generator, argmax(p / q) - the SAME token from the
+    same generator state (tests/test_gpu_kernels.py draws both ways from cloned states), without the twelve launches that validate the
+    row first (max < inf, min >= 0, sum > 0: two device-side asserts) - the row comes from `lade_softmax_rows`, which cannot produce
+    what they reject unless the logits were not finite.  Returns the index as an int64 tensor [1] on the row's device."""
+    q = torch.empty_like(probs_row).exponential_(1.0, generator=generator)
+    torch.div(probs_row, q, out=q)
+    return torch.argmax(q, dim=-1, keepdim=True)
+
+
 def final_distribution(probs_row: torch.Tensor, struck: Sequence[int]) -> torch.Tensor:
     """probs_row [V] fp32 (any device, consumed): the drafts rejected under this row are removed one at a time, renormalising
     after each (lade/decoding.py:519-520) - the arithmetic of the reference, on the one row that is actually sampled from."""

@@ -686,3 +686,21 @@ def test_softmax_rows_register_resident_and_fallback_paths():
         x = (torch.randn(2, 32001, device="cuda") * 3).to(dt)
         out = ops.softmax_rows(x[1:2], 0.9)
         assert torch.allclose(out, torch.softmax(x[1:2].float() / 0.9, dim=-1), rtol=2e-4, atol=1e-8)
+
+
+def test_multinomial_one_is_torch_multinomial_on_the_device():
+    """sampling.multinomial_one = torch.multinomial(p, 1, generator) minus its input checks: same token, same generator state afterwards,
+    device generators (what `LookaheadDecoder._draw` uses when the draw stays on the GPU, lade/decoding.py:484-540)"""
+    from lookaheaddecoding_amd.sampling import multinomial_one
+    for V in (5, 32000, 128256):
+        p = torch.softmax(torch.randn(V, generator=torch.Generator().manual_seed(V)) * 3, 0).cuda()
+        p[V // 2] = 0.0
+        g1, g2 = torch.Generator(device="cuda"), torch.Generator(device="cuda")
+        for seed in range(40):
+            g1.manual_seed(seed)
+            g2.manual_seed(seed)
+            for _ in range(3):                                   # consecutive draws: the generator offset advances alike
+                a = torch.multinomial(p, 1, generator=g1)
+                b = multinomial_one(p, g2)
+                assert a.item() == b.item() and b.dtype == torch.int64 and b.shape == (1,)
+            assert torch.equal(g1.get_state(), g2.get_state())

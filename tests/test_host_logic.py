@@ -246,3 +246,17 @@ def test_flash_lookahead_tuple_maps_onto_the_closed_form_mask():
     assert n > 300
     assert mask_from_lookahead([0, 0, 0, 40, 0, 0, 0], 9, 49) == StepMask(T=9, P=40, is_prefill=True)
     assert mask_from_lookahead(None, 9, 49) == StepMask(T=9, P=40, is_prefill=True)
+
+
+def test_multinomial_one_is_torch_multinomial():
+    """the device draw's replacement for torch.multinomial(p, 1) must take the same token from the same generator state and leave the
+    generator where torch leaves it (CPU generators here; tests/test_gpu_kernels.py repeats it with device generators)"""
+    import torch
+    from lookaheaddecoding_amd.sampling import multinomial_one
+    for V in (5, 257, 32000):
+        p = torch.softmax(torch.randn(V, generator=torch.Generator().manual_seed(V)) * 3, 0)
+        p[V // 2] = 0.0
+        for seed in range(60):
+            g1, g2 = torch.Generator().manual_seed(seed), torch.Generator().manual_seed(seed)
+            assert torch.multinomial(p, 1, generator=g1).item() == multinomial_one(p, g2).item()
+            assert torch.equal(g1.get_state(), g2.get_state())
