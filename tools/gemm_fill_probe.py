@@ -34,9 +34,10 @@ def timeit(fn, reps=40, rounds=5):
 
 a = torch.randn(M, K, device="cuda").bfloat16()
 for rep in range(2):
-    for (bn, mt, nt, wgs) in ((128, 2, 1, 216), (128, 2, 1, 256), (128, 2, 1, 240), (96, 2, 1, 256), (96, 2, 1, 216), (64, 2, 1, 256), (160, 0, 0, 0)):
-        if not wgs:
-            continue
+    cases = ((128, 2, 1, 216), (128, 2, 1, 256), (128, 2, 1, 240), (96, 2, 1, 256), (96, 2, 1, 216), (64, 2, 1, 256))
+    if os.environ.get("CASES"):            # "bn:mt:nt:wgs,..."
+        cases = tuple(tuple(int(x) for x in c.split(":")) for c in os.environ["CASES"].split(","))
+    for (bn, mt, nt, wgs) in cases:
         N = bn * wgs
         n_w = max(3, int(700e6 / (N * K * 2)))
         kts = [ops.to_ktile((torch.randn(N, K, device="cuda") * 0.02).bfloat16()) for _ in range(n_w)]
@@ -45,7 +46,7 @@ for rep in range(2):
 
         def run():
             i[0] = (i[0] + 1) % n_w
-            ops.gemm_swiglu(a, kts[i[0]], act, bn, mb, mt, nt, 3)
+            ops.gemm_swiglu(a, kts[i[0]], act, bn, mb, mt, nt, int(os.environ.get('RING', '3')))
         t = timeit(run)
         print(f"M={M} K={K} bn={bn} x {wgs} work-groups (N={N}, {N * K * 2 / 1e6:.0f} MB): {t:6.2f} us  {N * K * 2 / 1e6 / t:4.2f} TB/s  {bn * K * 2 / 1e3 / t:5.1f} GB/s per work-group", flush=True)
         del kts
