@@ -282,6 +282,8 @@ def worker(args):
     max_seq = args.prompt_len + total_steps * N + (N - 1) * (W + G) + 64
     if int(os.environ.get("WORLD_SIZE", 1)) > 1:                  # + the reference-default configuration run by the same ranks (lp_default)
         max_seq = max(max_seq, args.prompt_len + (7 + args.warmup + args.steps) * 8 + 7 * 120 + 128)
+    if os.environ.get("LADE_BENCH_MAX_SEQ"):                      # experiments: the KV cache's capacity (= the stride of its rows) as another tree sized it
+        max_seq = int(os.environ["LADE_BENCH_MAX_SEQ"])
     cfg["max_pos"] = max(cfg.get("max_pos", 4096), max_seq)
     weights = random_weights_torch(cfg, seed=0, dtype=dtype, device=dev)
     eng = StepEngine(cfg, weights, dtype=dtype, device=dev, max_seq=max_seq, max_T=args.chunk, consume_weights=True)

@@ -84,6 +84,7 @@ class LadeState:
         return self.record_host.tolist()
 
     POLL_TIMEOUT_S = float(os.environ.get("LADE_POLL_TIMEOUT_MS", "250")) * 1e-3
+    POLL_READS_PER_YIELD = max(1, int(os.environ.get("LADE_POLL_READS_PER_YIELD", "256")))
 
     def poll_record(self, step_no: int, timeout_s: Optional[float] = None) -> Optional[List[int]]:
         """The record of step `step_no` as `lade_greedy_post_step` stored it into the pinned host buffer (mapped into the device: no
@@ -97,7 +98,7 @@ class LadeState:
         buf = self.record_host_np
         deadline = time.monotonic() + (self.POLL_TIMEOUT_S if timeout_s is None else timeout_s)
         while True:
-            for _ in range(256):
+            for _ in range(self.POLL_READS_PER_YIELD):
                 if buf[7] == step_no:
                     rec = buf.tolist()
                     if rec[7] == step_no and (rec[REC_WORDS - 1] & 0xFFFFFFFF) == record_seal(rec, step_no):

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--lp-rank", action="store_true", help="a lookahead-parallel rank's step instead of the full window: 4 re-fed inputs, "
                     "columns 12..14 of the W=15 window, 2 candidates (T = 31; with --H 64 --Hkv 8 this is config 5's rank shape)")
     ap.add_argument("--wg", type=int, default=0, help="work-group rows (lade_attn_args.wg_rows): 0 = default, 128 | 64 | 32")
+    ap.add_argument("--smax", type=int, nargs="+", default=[0], help="cache capacity in rows (the stride of the V^T rows and of the K heads): 0 = just above P + T")
     ap.add_argument("--W", type=int, default=15)
     ap.add_argument("--N", type=int, default=5)
     a = ap.parse_args()
@@ -31,8 +32,8 @@ def main():
     for T in a.T:
         g = max(0, (T - (N - 1) * W) // gs)
         T = (N - 1) * W + g * gs
-        for P in a.P:
-            S_max = (P + T + 63) // 64 * 64 + 64
+        for P, smax in ((P, sm) for P in a.P for sm in a.smax):
+            S_max = max(smax, (P + T + 63) // 64 * 64) if smax else (P + T + 63) // 64 * 64 + 64
             q = torch.randn(T, (a.H + 2 * a.Hkv) * a.d, device="cuda").bfloat16()
             # enough distinct caches that their total exceeds the Infinity Cache (256 MB): every launch reads HBM; --resident keeps one
             per = 2 * a.Hkv * S_max * a.d * 2
@@ -63,7 +64,7 @@ def main():
                           " WG start spread:", int(tl[:, 0].max() - tl[:, 0].min()), " kernel span:", int(tl[:, 6].max() - tl[:, 0].min()))
                 else:
                     us = ops.time_attn(q, k, vt, mask, H=a.H, Hkv=a.Hkv, d=a.d, n_splits=n, reps=a.reps, wg_rows=a.wg)
-                print(f"H={a.H:3d}/{a.Hkv:2d} T={T:4d} P={P:5d} splits={n:3d} wg={a.wg or 128:3d}  {us:8.2f} us   {alg / us / 1e3:8.1f} GB/s  ({alg / us / 1e3 / 8000 * 100:5.1f}% of 8 TB/s)", flush=True)
+                print(f"H={a.H:3d}/{a.Hkv:2d} T={T:4d} P={P:5d} S_max={S_max:5d} splits={n:3d} wg={a.wg or 128:3d}  {us:8.2f} us   {alg / us / 1e3:8.1f} GB/s  ({alg / us / 1e3 / 8000 * 100:5.1f}% of 8 TB/s)", flush=True)
 
 
 if __name__ == "__main__":
