@@ -704,3 +704,46 @@ def test_multinomial_one_is_torch_multinomial_on_the_device():
                 b = multinomial_one(p, g2)
                 assert a.item() == b.item() and b.dtype == torch.int64 and b.shape == (1,)
             assert torch.equal(g1.get_state(), g2.get_state())
+
+
+def test_rmsnorm_every_block_shape_vs_torch():
+    """lade_rmsnorm / lade_add_rmsnorm / the split-K-partials form at every work-group shape of the dispatch (one 16-byte chunk per thread
+    on 256 / 512 / 640 / 768 / 1024 threads, then 2 and 4 chunks: hidden 2048 ... 32768; LlamaRMSNorm, modeling_llama.py:76-91) against
+    the fp32 statement of the op with the reference's rounding points.  Tolerances: fp32 1e-6 / 1e-5, 16-bit 2e-2 / 2e-2 (one rounding
+    of the normalised value, one of the product); the residual sum written back to x is exact."""
+    from lookaheaddecoding_amd import ops
+    torch.manual_seed(3)
+    for dtype in (torch.bfloat16, torch.float16, torch.float32):
+        per16 = 4 if dtype == torch.float32 else 8
+        for hidden in (2048, 4096, 5120, 6144, 8192, 16384, 32768):
+            if hidden // per16 > 4096:
+                continue                                  # beyond the register-resident row (LADE_E_LIMIT)
+            rows = 7
+            x = torch.randn(rows, hidden).to(dtype)
+            r = torch.randn(rows, hidden).to(dtype)
+            w = (1 + 0.1 * torch.randn(hidden)).to(dtype)
+
+            def ref_norm(h):
+                v = h.float().pow(2).mean(-1, keepdim=True)
+                return (w.float() * (h.float() * torch.rsqrt(v + 1e-5)).to(dtype).float()).to(dtype)
+
+            tol = dict(atol=1e-6, rtol=1e-5) if dtype == torch.float32 else dict(atol=2e-2, rtol=2e-2)
+            y = ops.rmsnorm(x.cuda(), w.cuda(), 1e-5).cpu()
+            assert torch.allclose(y.float(), ref_norm(x).float(), **tol), (dtype, hidden)
+            xd = x.cuda().clone()
+            y2 = ops.add_rmsnorm(xd, r.cuda(), w.cuda(), 1e-5).cpu()
+            assert torch.equal(xd.cpu(), x + r), (dtype, hidden)
+            assert torch.allclose(y2.float(), ref_norm(x + r).float(), **tol), (dtype, hidden)
+            if dtype == torch.float32:
+                continue
+            for n_parts in (2, 6, 9):
+                part = torch.randn(n_parts, rows, hidden, device="cuda")
+                rsum = part[0].clone()
+                for j in range(1, n_parts):
+                    rsum += part[j]                       # split order, fp32, rounded once
+                xs = x + rsum.to(dtype).cpu()
+                xd = x.cuda().clone()
+                y3 = torch.empty_like(xd)
+                ops.add_rmsnorm_parts(xd, part, n_parts, w.cuda(), 1e-5, y3)
+                assert torch.equal(xd.cpu(), xs), (dtype, hidden, n_parts)
+                assert torch.allclose(y3.cpu().float(), ref_norm(xs).float(), **tol), (dtype, hidden, n_parts)
