@@ -58,7 +58,8 @@
 extern "C" {
 #endif
 
-#define LADE_ABI_VERSION 2      /* 2: lade_attn_args grew (wg_rows, fused RoPE), lade_gemm_skinny* take `ring`, lade_greedy_post_step takes record_host */
+#define LADE_ABI_VERSION 3      /* 2: lade_attn_args grew (wg_rows, fused RoPE), lade_gemm_skinny* take `ring`, lade_greedy_post_step takes record_host;
+                                 * 3: + lade_gemm_ra_kt, lade_build_flags (nothing that existed changed) */
 
 /* error codes */
 #define LADE_OK 0
@@ -402,6 +403,14 @@ int lade_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, voi
 int lade_gemm_skinny_kt(const void* A, int64_t lda, const void* Wkt, void* C, int64_t ldc, float* Cpart,
                         int32_t M, int32_t N, int32_t K, int32_t n_split, int32_t bn, int32_t mb, int32_t mt, int32_t nt,
                         int32_t ring, int32_t epilogue, int32_t dtype, void* stream);
+/* Split-K GEMM with REGISTER-RESIDENT activations for steps of M <= 128 rows (the same projections, lade/models/modeling_llama.py:360-380,
+ * 492-494, 558): a work-group is persistent over the weight rows of its column group and keeps the activation fragments of its K slice
+ * (<= 20 K tiles = 1280 deep: ceil(K / 64 / n_split) <= 20) in registers, so the activations pass through a CU once per work-group and the
+ * whole LDS is a ring of weight tiles.  Writes fp32 partials Cpart[n_split][M][N] for a `*_parts` consumer - bit-identical to
+ * lade_gemm_skinny_kt's with the same n_split.  cs = 32-row weight strips per chunk (2 | 4; N % (32 cs) == 0), n_groups = column groups
+ * per split (0 = CUs / n_split; the launch has n_groups * n_split work-groups, one per CU). */
+int lade_gemm_ra_kt(const void* A, int64_t lda, const void* Wkt, float* Cpart, int32_t M, int32_t N, int32_t K, int32_t n_split,
+                    int32_t cs, int32_t n_groups, int32_t dtype, void* stream);
 int lade_weight_to_ktile(const void* W, int64_t ldw, void* Wkt, int32_t N, int32_t K, int32_t dtype, void* stream);
 /* the inverse, into a caller-provided row-major scratch W[N][ldw]: what a library GEMM needs (prefill chunks wider than 256 rows) when a
  * model too large to be held twice keeps its projection weights K-tile-major only */
@@ -421,6 +430,9 @@ int lade_splitk_reduce(const float* part, void* C, int64_t ldc, int32_t M, int32
 
 /* ---- misc ------------------------------------------------------------------------------- */
 int lade_version(void);
+/* what this build of the library contains: bit 0 = the experimental attention forms (RoPE + KV append inside the launch: lade_attn_args.n_parts > 0,
+ * sync_flags; built with `make EXPERIMENTAL=1`, measured slower than the two-launch form at every BASELINE shape) */
+int lade_build_flags(void);
 const char* lade_last_error_string(void);
 /* kernel timing helper for bench.py: runs `reps` launches of lade_attn_fwd (+combine) on `stream`
  * bracketed by hipEvents and returns the mean duration of one launch pair in microseconds. */

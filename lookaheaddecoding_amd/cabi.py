@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LADE_HIP_LIB") or os.path.join(_HERE, "liblade_hip.so")     # env override: kernel experiments
 
-ABI_VERSION = 2           # LADE_ABI_VERSION of include/lade_hip.h this binding was written against (checked at load time)
+ABI_VERSION = 3           # LADE_ABI_VERSION of include/lade_hip.h this binding was written against (checked at load time)
 LADE_BF16, LADE_F16, LADE_F32 = 0, 1, 2
 DTYPE_CODE = {torch.bfloat16: LADE_BF16, torch.float16: LADE_F16, torch.float32: LADE_F32}
 
@@ -100,6 +100,7 @@ SIGNATURES = {
     "lade_gather_rows": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "lade_gemm_skinny": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "lade_gemm_skinny_kt": [_vp, _i64, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "lade_gemm_ra_kt": [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "lade_weight_to_ktile": [_vp, _i64, _vp, _i32, _i32, _i32, _vp],
     "lade_weight_from_ktile": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
     "lade_add_rmsnorm_parts": [_vp, _vp, _i32, _i64, _vp, _vp, _i32, _i32, _f32, _i32, _vp],
@@ -108,6 +109,7 @@ SIGNATURES = {
     "lade_splitk_reduce": [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
     "lade_record_seal": [C.POINTER(C.c_uint32), C.c_uint32],
     "lade_version": [],
+    "lade_build_flags": [],
     "lade_last_error_string": [],
     "lade_time_attn": [C.POINTER(AttnArgs), _i32, C.POINTER(C.c_float), _vp],
     "lade_time_attn_rot": [C.POINTER(AttnArgs), _i32, _i32, C.POINTER(C.c_float), _vp],
@@ -142,6 +144,11 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
 
 def lib() -> C.CDLL:
     return load_library()
+
+
+def experimental() -> bool:
+    """whether the loaded library was built with -DLADE_EXPERIMENTAL (the attention forms with RoPE + KV append inside the launch)"""
+    return bool(lib().lade_build_flags() & 1)
 
 
 def stream_ptr() -> int:

@@ -379,14 +379,16 @@ __device__ __forceinline__ void rope_producer(const AttnK& a, unsigned char* sme
     const int n_rep = a.n_rep;
     const bool writes = P + a.m.T <= a.S_max;                   // (a device-side cache length past the cache: nothing is written, as in lade_rope_kv_append)
     uint16_t* q_out = const_cast<uint16_t*>(a.q);
-    if (writes) {
-        // q rows of the group's heads + the K row: one item = 8 + 8 values (columns i.., i + D/2..) of one head row
+    {
+        // q rows of the group's heads + the K row: one item = 8 + 8 values (columns i.., i + D/2..) of one head row.  The q rows are rotated
+        // whatever the cache length (the two-launch form does the same); only the cache stores are skipped past the cache.
         const int per_tok = (n_rep + 1) * VPH;
         for (int idx = tid; idx < nt_ * per_tok; idx += NTHR) {
             const int tt = idx / per_tok, rem = idx - tt * per_tok, hs = rem / VPH, i = (rem - hs * VPH) * 8;
             const int t = t0 + tt;
             int trow = t;
             if (a.positions) { trow = a.positions[t]; trow = trow < 0 ? 0 : (trow >= a.max_pos ? a.max_pos - 1 : trow); }
+            if (hs >= n_rep && !writes) continue;
             const size_t col = hs < n_rep ? (size_t)(kvh * n_rep + hs) * D : (size_t)(a.H + kvh) * D;
             RopeItem<NPC> it;
             rope_load<NPC, D>(it, a, (size_t)t * a.row_w + col + i, trow, i);
@@ -397,6 +399,8 @@ __device__ __forceinline__ void rope_producer(const AttnK& a, unsigned char* sme
             store_wt_b128(dst, o1);
             store_wt_b128(dst + D / 2, o2);
         }
+    }
+    if (writes) {
         // V rows: partials summed in split order, rounded once, transposed through LDS ([token][d], padded rows)
         uint16_t* stage_v = reinterpret_cast<uint16_t*>(smem);
         const size_t v_col = (size_t)(a.H + a.Hkv + kvh) * D;
@@ -618,6 +622,7 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
 #pragma unroll
         for (int ts = 0; ts < TPS; ++ts) issue_tiles(stage, ts, tile_of(j, ts));
     };
+    float pm_poison = 0.f;               // producer mode: NaN once this work-group's wait for its producers has timed out
     bool pm_wait_all = false;            // producer mode: q was requested AFTER the first stages - the loop's first wait covers everything
     int store_fence_at = -1;             // fused: the loop iteration behind which the first tile holding a row this work-group stored is requested
     if constexpr (NPC == 0) {
@@ -640,10 +645,15 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
             } else {
                 for (int s = 0; s < early; ++s) issue_stage(s, s);
             }
-            if (tid == 0) {                          // ONE lane polls (relaxed, device scope: an sc1 load), bounded: ~0.1 s, then the launch ends wrong rather than never
+            if (tid == 0) {                          // ONE lane polls (relaxed, device scope: an sc1 load), bounded: ~0.1 s
                 int spins = 0;
                 while (__hip_atomic_load(a.flags + kvh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.prod_chunks && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(2);
+                *reinterpret_cast<volatile int*>(q_lds) = spins >= (1 << 20);
             }
+            wg_barrier();
+            // a poll that ran out must not end as plausible numbers: the work-group's row sums become NaN, and with them the merged output rows
+            // (the Q tile is free until issue_q below: the word is read by every thread between two barriers)
+            if (*reinterpret_cast<volatile int*>(q_lds)) pm_poison = __builtin_nanf("");
             wg_barrier();
             sc1_from_q = first_new_q;                // from here on the tiles that hold new rows are requested with sc1 loads
             issue_q(std::true_type{});
@@ -790,7 +800,7 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
     for (int i = 0; i < DBLK; ++i)
 #pragma unroll
         for (int j = 0; j < 16; ++j) oacc[i][j] = 0.f;
-    float m_run = NEG_BIG, l_run = 0.f;
+    float m_run = NEG_BIG, l_run = pm_poison;
     const int krow = 32 * kh + kappa(ql);          // LDS row (key within the tile) of this lane's MFMA row
 
     for (int i = 0; i < nt; ++i) {
@@ -1157,6 +1167,7 @@ static int validate(const lade_attn_args* a) {
         LADE_REQUIRE(a->positions || a->max_pos >= a->mask.T, LADE_E_ARG, "lade_attn: fused RoPE without positions reads table rows 0..T-1 (max_pos=%d, T=%d)", a->max_pos, a->mask.T);
         LADE_REQUIRE(a->dtype == LADE_BF16 || a->dtype == LADE_F16, LADE_E_DTYPE, "lade_attn: fused RoPE is built for bf16 / f16 (dtype=%d)", a->dtype);
         LADE_REQUIRE(a->part_stride >= (int64_t)a->mask.T * (a->H + 2 * a->Hkv) * a->d, LADE_E_ARG, "lade_attn: part_stride %lld is shorter than one partial", (long long)a->part_stride);
+        LADE_REQUIRE(!a->sync_flags || a->Hkv <= 256, LADE_E_LIMIT, "lade_attn: the producer mode's flags are reset by one 256-thread block of lade_attn_combine: Hkv=%d > 256", a->Hkv);
         LADE_REQUIRE(!a->sync_flags || (a->q && a->n_splits > 1 && a->q_row_stride % 8 == 0), LADE_E_ARG,
                      "lade_attn: the producer mode of the fused RoPE (sync_flags) writes the rotated q rows to `q` and is reset by lade_attn_combine: it needs q and n_splits > 1");
     } else {
@@ -1237,7 +1248,13 @@ static int launch_fwd_npc(const lade_attn_args* a, hipStream_t st) {
 template <typename T, int D>
 static int launch_fwd(const lade_attn_args* a, hipStream_t st) {
     if (a->n_parts == 0) return launch_fwd_npc<T, D, 0>(a, st);
+#ifdef LADE_EXPERIMENTAL
+    // RoPE + KV append inside the attention launch (two forms, both bit-identical to the two-launch form and both measured SLOWER at every
+    // BASELINE shape: DESIGN 4.9, profiles/r5_fused_rope_ab.txt): built only with -DLADE_EXPERIMENTAL (make EXPERIMENTAL=1)
     return a->n_parts <= 2 ? launch_fwd_npc<T, D, 2>(a, st) : launch_fwd_npc<T, D, 4>(a, st);
+#else
+    LADE_REQUIRE(false, LADE_E_ARG, "lade_attn: the fused RoPE + KV append forms (n_parts > 0) are not in this build (make EXPERIMENTAL=1; lade_build_flags() bit 0)");
+#endif
 }
 
 }  // namespace lade

@@ -27,6 +27,13 @@ int check_launch(const char* what) {
 }  // namespace lade
 
 extern "C" int lade_version(void) { return LADE_ABI_VERSION; }
+extern "C" int lade_build_flags(void) {
+#ifdef LADE_EXPERIMENTAL
+    return 1;
+#else
+    return 0;
+#endif
+}
 extern "C" const char* lade_last_error_string(void) { return lade::g_err; }
 
 // Mean duration (us) of `reps` back-to-back launches of the attention kernel pair on `stream`,

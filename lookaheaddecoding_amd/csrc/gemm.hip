@@ -118,6 +118,40 @@ extern "C" int lade_gemm_skinny_kt(const void* A, int64_t lda, const void* Wkt, 
     return gemm_skinny(A, lda, Wkt, 8, true, C, ldc, Cpart, M, N, K, n_split, bn, mb, mt, nt, ring, epilogue, dtype, stream);
 }
 
+// Split-K GEMM with register-resident activations (gemm_ra.hpp): M <= 128 rows, K-tile-major weights, fp32 partials for a `*_parts`
+// consumer.  The K slices are those of lade_gemm_skinny_kt with the same n_split, and so are the partials - bit for bit.
+extern "C" int lade_gemm_ra_kt(const void* A, int64_t lda, const void* Wkt, float* Cpart, int32_t M, int32_t N, int32_t K, int32_t n_split,
+                               int32_t cs, int32_t n_groups, int32_t dtype, void* stream) {
+    LADE_REQUIRE(A && Wkt && Cpart && M > 0 && M <= 128 && N > 0 && K > 0 && n_split >= 1, LADE_E_ARG, "lade_gemm_ra_kt: M=%d (1..128) N=%d K=%d split=%d", M, N, K, n_split);
+    LADE_REQUIRE(K % G_BK == 0 && lda % 8 == 0 && (cs == 2 || cs == 4) && N % (32 * cs) == 0, LADE_E_ARG,
+                 "lade_gemm_ra_kt: K=%d must be a multiple of %d, lda of 8, cs=%d one of 2 | 4, N=%d a multiple of 32 cs", K, G_BK, cs, N);
+    LADE_REQUIRE(dtype == LADE_BF16 || dtype == LADE_F16, LADE_E_DTYPE, "lade_gemm_ra_kt: dtype=%d", dtype);
+    const int k_tiles = K / G_BK, tps = (k_tiles + n_split - 1) / n_split;
+    LADE_REQUIRE(tps <= RA_KT && (n_split - 1) * tps < k_tiles, LADE_E_ARG,
+                 "lade_gemm_ra_kt: K=%d in %d splits = %d K tiles per work-group (a work-group holds <= %d in registers; no split may be empty)", K, n_split, tps, RA_KT);
+    LADE_REQUIRE((int64_t)lda * 128 * 2 < ((int64_t)1 << 31), LADE_E_LIMIT, "lade_gemm_ra_kt: lda=%lld too large", (long long)lda);
+    if (n_groups <= 0) {
+        static int n_cu = 0;
+        if (n_cu == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        }
+        n_groups = n_cu / n_split > 0 ? n_cu / n_split : 1;
+    }
+    const int nc = N / (32 * cs);
+    if (n_groups > nc) n_groups = nc;
+    GemmRA g;
+    g.A = (const uint16_t*)A; g.W = (const uint16_t*)Wkt; g.Cpart = Cpart; g.lda = lda;
+    g.M = M; g.N = N; g.K = K; g.n_split = n_split; g.tps = tps; g.n_groups = n_groups;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("LADE_GEMM_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
+    const int mw = (M + 31) / 32;
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = dtype == LADE_BF16 ? gemm_ra_dispatch_bf16(g, st, mw, cs) : gemm_ra_dispatch_f16(g, st, mw, cs);
+    if (rc >= 0) return rc;
+    LADE_REQUIRE(false, LADE_E_ARG, "lade_gemm_ra_kt: no kernel for %d row blocks x %d-strip chunks", mw, cs);
+}
+
 // Wkt[kt][n][0..63] = W[n][64 kt .. 64 kt + 63]: one 16-byte chunk per thread, a wave writes 1 KiB contiguous
 extern "C" int lade_weight_to_ktile(const void* W, int64_t ldw, void* Wkt, int32_t N, int32_t K, int32_t dtype, void* stream) {
     LADE_REQUIRE(W && Wkt && W != Wkt && N > 0 && K > 0 && K % G_BK == 0 && ldw >= K && ldw % 8 == 0, LADE_E_ARG,

@@ -23,6 +23,22 @@ struct GemmK {
                            // 2 = row argmax: no C, Cpart holds one (value, column) pair per row and column block
 };
 
+// register-resident-activation kernel (gemm_ra.hpp)
+struct GemmRA {
+    const uint16_t* A;     // [M][lda]
+    const uint16_t* W;     // K-tile-major [K/64][N][64]
+    float* Cpart;          // [n_split][M][N] fp32
+    int64_t lda;
+    int M, N, K;
+    int n_split, tps;      // K tiles per split (<= KT; the last split may hold fewer)
+    int n_groups;          // column groups per split; grid = n_groups * n_split work-groups
+    int dbg;               // 1 = no stores, 4 = no fragment reads / MFMA (tools)
+};
+
+constexpr int RA_KT = 20;          // K tiles (64 deep) a work-group of the RA kernel holds in registers: K slices of <= 1280
+int gemm_ra_dispatch_bf16(const GemmRA& g, hipStream_t st, int mw, int cs);
+int gemm_ra_dispatch_f16(const GemmRA& g, hipStream_t st, int mw, int cs);
+
 // launch the kernel built for this wave grid (mw x ng waves compute, mt x nt MFMA tiles each); -1 when it is not in the shape table
 int gemm_dispatch_bf16(const GemmK& g, hipStream_t st, int mw, int mt, int ng, int nt);
 int gemm_dispatch_f16(const GemmK& g, hipStream_t st, int mw, int mt, int ng, int nt);

@@ -61,135 +61,15 @@ template <> struct GMfma<F16> {
 // value after one rounding to the model dtype (the GEMM output, then every elementwise op, rounds like torch does)
 template <typename T> __device__ __forceinline__ float g_rnd(float f) { return to_f32<T>(from_f32<T>(f)); }
 
-// Work-group tile = BM activation rows x BN weight rows, BM = 32*MW*MT, BN = 32*NG*NT: the waves form an MW x NG grid
-// (MW*NG <= 8 waves compute, all 8 issue DMA; m-group = w % MW, n-group = w / MW) and one wave owns MT x NT MFMA tiles
-// of 32 x 32.  Per 16-deep K step a wave reads MT activation + NT weight fragments from LDS for MT*NT MFMAs, so the LDS
-// bytes read per weight byte are 8 waves * (MT + NT) / (NG*NT) ... = (MT + NT) / NT * MW (+ the DMA write): with MT = 1 a
-// 128-row step moves ~7 LDS bytes per weight byte and the 128 B/clk LDS port caps a CU at ~38 GB/s of weights; 2 x 2
-// wave tiles bring that to ~5.5.
+// Epilogue shared by the kernels of this file: the C^T tile a work-group holds in its accumulators (wave (mw, ng) of an MW x NG grid, MT x NT MFMA
+// tiles each; lane = activation row ql of an m-tile, 16 weight rows per tile) -> row-major C / SwiGLU / row argmax / fp32 split-K partials.
+// Every wave of the work-group calls it (barriers inside); `computes` = this wave holds accumulators.
 template <typename T, int MW, int MT, int NG, int NT>
-__global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
-    static_assert(MW * NG <= 8, "at most 8 computing waves");
-    constexpr int NW = G_THREADS / 64;          // all 8 waves move DMA pieces, the first MW * NG of them compute
-    constexpr int MB = MW * MT;
+__device__ __forceinline__ void gemm_epilogue(const GemmK& g, f32x16 (&acc)[MT][NT], unsigned char* smem, int mw, int ng, bool computes, int n0, int m0, int split) {
     constexpr int BN = 32 * NT * NG;
-    constexpr int BM = 32 * MB;
-    // a stage = one 64-deep K tile: [weight tile | activation tile]
-    constexpr int W_BYTES = BN * 128, A_BYTES = BM * 128, STAGE = W_BYTES + A_BYTES;
-    constexpr int W_PIECES = W_BYTES / 1024, A_PIECES = A_BYTES / 1024;      // 1-KiB DMA pieces per tile
-    constexpr int TOTAL_PIECES = W_PIECES + A_PIECES;
-    constexpr int PIECES = (TOTAL_PIECES + NW - 1) / NW;                     // per wave and stage (the tail repeats the last piece)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BM = 32 * MW * MT;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mw = wave % MW, ng = wave / MW;
-    const bool computes = ng < NG;
     const int ql = lane & 31, hi = lane >> 5;
-    const int n0 = blockIdx.x * BN, split = blockIdx.y, m0 = blockIdx.z * BM;
-
-    const int k_tiles = (g.K + G_BK - 1) / G_BK;
-    const int tps = (k_tiles + g.n_split - 1) / g.n_split;
-    const int t0 = split * tps;
-    const int nt = max(0, min(t0 + tps, k_tiles) - t0);
-
-    // ---- this wave's DMA pieces, resolved ONCE: per piece a lane's source pointer at the split's first K tile and the piece's offset
-    // inside a stage.  Inside the K loop a piece then costs one 64-bit add, the M0 write
-    // and the global_load_lds.  (Left inside the loop, the address arithmetic - two clamps, a 64-bit multiply, and the kernel
-    // arguments re-read through the scalar cache after every asm barrier - cost a wave ~120 ns per piece: more than the transfer.)
-    // weight addressing: row-major W[N][ldw] (a K tile of a row = 128 bytes, rows ldw apart) or K-tile-major Wkt[K/64][N][64] (g.w_ts =
-    // 64 N: the 128-byte segments of ALL rows of one K tile are contiguous, so a 1-KiB DMA piece is one contiguous KiB, a work-group's
-    // tile one contiguous BN x 128 bytes, and the work-groups of a split sweep memory linearly as they walk along K)
-    const int64_t w_rs = g.w_ts ? G_BK : g.ldw, w_ts = g.w_ts ? g.w_ts : G_BK;
-    const bool moves = wave * PIECES < TOTAL_PIECES;     // a wave moves PIECES pieces or none (vmcnt is per wave: nothing requested, nothing to wait for)
-    const uint16_t* p_src[PIECES];
-    int p_dst[PIECES];
-    bool p_w[PIECES];
-    const bool nt_weights = !(g.dbg & 16);
-#pragma unroll
-    for (int i = 0; i < PIECES; ++i) {
-        const int piece = min(wave * PIECES + i, TOTAL_PIECES - 1);
-        const bool isw = piece < W_PIECES;
-        const int p = isw ? piece : piece - W_PIECES;
-        const int row = p * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
-        p_src[i] = (isw ? g.W + (size_t)min(n0 + row, g.N - 1) * w_rs + (size_t)t0 * w_ts
-                        : g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + (size_t)t0 * G_BK) + c * 8;
-        if (!isw && (g.dbg & 128)) p_src[i] = g.A + (lane & 7) * 8;        // ablation (tools/gemm_ingest_probe.py): every activation piece re-reads one cached 128-byte line
-        p_dst[i] = (isw ? 0 : W_BYTES) + p * 1024;
-        p_w[i] = isw;
-    }
-    // tile j of this split into ring slot `stage`
-    auto issue = [&](int j, int stage) {
-        if (!moves) return;
-        unsigned char* sbase = smem + stage * STAGE;
-#pragma unroll
-        for (int i = 0; i < PIECES; ++i) {
-            const uint16_t* src = p_src[i] + (int64_t)j * (p_w[i] ? w_ts : ((g.dbg & 128) ? (int64_t)0 : (int64_t)G_BK));
-            unsigned char* dst = sbase + p_dst[i];
-            // the weight stream is non-temporal (aux = 2): every weight byte is read by exactly one work-group, once per step, so
-            // keeping it in L2 / the Infinity Cache only evicts what is re-read (activation tiles, partials).  Measured on the four
-            // 7B projections at 60 rows: 97.2 -> 92.0 us per layer, decode step 4.65 -> 4.51 ms (LADE_GEMM_DBG=16 turns it off)
-            if (p_w[i] && nt_weights)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 2);
-            else
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
-    };
-
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int a = 0; a < MT; ++a)
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][i][e] = 0.f;
-
-    // The ring depth is a launch parameter, but the loop is compiled once per depth (the counted waits need immediates, and a run-time
-    // chain of compare-and-branch per K tile in front of every barrier cost the step 6 %: 4.29 / 4.33 vs 4.05 / 4.10 ms against the
-    // compile-time ring on one box); the kernel switches to its copy once.
-    auto main_loop = [&](auto ns_c) __attribute__((always_inline)) {
-        constexpr int NS = decltype(ns_c)::value;
-#pragma unroll
-        for (int s = 0; s < NS; ++s)
-            if (s < nt) issue(s, s);
-        for (int i = 0; i < nt; ++i) {
-            const int stage = i % NS;
-            const int younger = min(nt, i + NS) - (i + 1);        // tiles requested after tile i that may stay in flight
-            g_wait_younger<PIECES, NS - 1>(younger);
-            g_barrier();
-            const unsigned char* ws = smem + stage * STAGE;
-            const unsigned char* as = ws + W_BYTES;
-            if (computes && !(g.dbg & 4))
-#pragma unroll
-            for (int kk = 0; kk < G_BK / 16; ++kk) {
-                u32x4 af[MT], wf[NT];
-#pragma unroll
-                for (int a = 0; a < MT; ++a) af[a] = *reinterpret_cast<const u32x4*>(as + g_off((mw * MT + a) * 32 + ql, kk * 2 + hi));
-#pragma unroll
-                for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const u32x4*>(ws + g_off((ng * NT + j) * 32 + ql, kk * 2 + hi));
-#pragma unroll
-                for (int a = 0; a < MT; ++a)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[a][j] = GMfma<T>::run(wf[j], af[a], acc[a][j]);
-            }
-            if (i + NS < nt) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                g_barrier();
-                issue(i + NS, stage);
-            }
-        }
-    };
-    switch (g.n_stage) {
-        case 2: main_loop(std::integral_constant<int, 2>{}); break;
-        case 3: main_loop(std::integral_constant<int, 3>{}); break;
-        case 5: main_loop(std::integral_constant<int, 5>{}); break;
-        case 6: main_loop(std::integral_constant<int, 6>{}); break;
-        case 8: main_loop(std::integral_constant<int, 8>{}); break;
-        default: main_loop(std::integral_constant<int, 4>{}); break;
-    }
-
     // ---- epilogue: C^T tile (lane = activation row ql of block mb, 16 weight rows per MFMA tile) -> row-major C ----
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     g_barrier();
@@ -348,6 +228,138 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
             }
         }
     }
+}
+
+// Work-group tile = BM activation rows x BN weight rows, BM = 32*MW*MT, BN = 32*NG*NT: the waves form an MW x NG grid
+// (MW*NG <= 8 waves compute, all 8 issue DMA; m-group = w % MW, n-group = w / MW) and one wave owns MT x NT MFMA tiles
+// of 32 x 32.  Per 16-deep K step a wave reads MT activation + NT weight fragments from LDS for MT*NT MFMAs, so the LDS
+// bytes read per weight byte are 8 waves * (MT + NT) / (NG*NT) ... = (MT + NT) / NT * MW (+ the DMA write): with MT = 1 a
+// 128-row step moves ~7 LDS bytes per weight byte and the 128 B/clk LDS port caps a CU at ~38 GB/s of weights; 2 x 2
+// wave tiles bring that to ~5.5.
+template <typename T, int MW, int MT, int NG, int NT>
+__global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
+    static_assert(MW * NG <= 8, "at most 8 computing waves");
+    constexpr int NW = G_THREADS / 64;          // all 8 waves move DMA pieces, the first MW * NG of them compute
+    constexpr int MB = MW * MT;
+    constexpr int BN = 32 * NT * NG;
+    constexpr int BM = 32 * MB;
+    // a stage = one 64-deep K tile: [weight tile | activation tile]
+    constexpr int W_BYTES = BN * 128, A_BYTES = BM * 128, STAGE = W_BYTES + A_BYTES;
+    constexpr int W_PIECES = W_BYTES / 1024, A_PIECES = A_BYTES / 1024;      // 1-KiB DMA pieces per tile
+    constexpr int TOTAL_PIECES = W_PIECES + A_PIECES;
+    constexpr int PIECES = (TOTAL_PIECES + NW - 1) / NW;                     // per wave and stage (the tail repeats the last piece)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mw = wave % MW, ng = wave / MW;
+    const bool computes = ng < NG;
+    const int ql = lane & 31, hi = lane >> 5;
+    const int n0 = blockIdx.x * BN, split = blockIdx.y, m0 = blockIdx.z * BM;
+
+    const int k_tiles = (g.K + G_BK - 1) / G_BK;
+    const int tps = (k_tiles + g.n_split - 1) / g.n_split;
+    const int t0 = split * tps;
+    const int nt = max(0, min(t0 + tps, k_tiles) - t0);
+
+    // ---- this wave's DMA pieces, resolved ONCE: per piece a lane's source pointer at the split's first K tile and the piece's offset
+    // inside a stage.  Inside the K loop a piece then costs one 64-bit add, the M0 write
+    // and the global_load_lds.  (Left inside the loop, the address arithmetic - two clamps, a 64-bit multiply, and the kernel
+    // arguments re-read through the scalar cache after every asm barrier - cost a wave ~120 ns per piece: more than the transfer.)
+    // weight addressing: row-major W[N][ldw] (a K tile of a row = 128 bytes, rows ldw apart) or K-tile-major Wkt[K/64][N][64] (g.w_ts =
+    // 64 N: the 128-byte segments of ALL rows of one K tile are contiguous, so a 1-KiB DMA piece is one contiguous KiB, a work-group's
+    // tile one contiguous BN x 128 bytes, and the work-groups of a split sweep memory linearly as they walk along K)
+    const int64_t w_rs = g.w_ts ? G_BK : g.ldw, w_ts = g.w_ts ? g.w_ts : G_BK;
+    const bool moves = wave * PIECES < TOTAL_PIECES;     // a wave moves PIECES pieces or none (vmcnt is per wave: nothing requested, nothing to wait for)
+    const uint16_t* p_src[PIECES];
+    int p_dst[PIECES];
+    bool p_w[PIECES];
+    const bool nt_weights = !(g.dbg & 16);
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+        const int piece = min(wave * PIECES + i, TOTAL_PIECES - 1);
+        const bool isw = piece < W_PIECES;
+        const int p = isw ? piece : piece - W_PIECES;
+        const int row = p * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        p_src[i] = (isw ? g.W + (size_t)min(n0 + row, g.N - 1) * w_rs + (size_t)t0 * w_ts
+                        : g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + (size_t)t0 * G_BK) + c * 8;
+        if (!isw && (g.dbg & 128)) p_src[i] = g.A + (lane & 7) * 8;        // ablation (tools/gemm_ingest_probe.py): every activation piece re-reads one cached 128-byte line
+        p_dst[i] = (isw ? 0 : W_BYTES) + p * 1024;
+        p_w[i] = isw;
+    }
+    // tile j of this split into ring slot `stage`
+    auto issue = [&](int j, int stage) {
+        if (!moves) return;
+        unsigned char* sbase = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const uint16_t* src = p_src[i] + (int64_t)j * (p_w[i] ? w_ts : ((g.dbg & 128) ? (int64_t)0 : (int64_t)G_BK));
+            unsigned char* dst = sbase + p_dst[i];
+            // the weight stream is non-temporal (aux = 2): every weight byte is read by exactly one work-group, once per step, so
+            // keeping it in L2 / the Infinity Cache only evicts what is re-read (activation tiles, partials).  Measured on the four
+            // 7B projections at 60 rows: 97.2 -> 92.0 us per layer, decode step 4.65 -> 4.51 ms (LADE_GEMM_DBG=16 turns it off)
+            if (p_w[i] && nt_weights)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 2);
+            else
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][i][e] = 0.f;
+
+    // The ring depth is a launch parameter, but the loop is compiled once per depth (the counted waits need immediates, and a run-time
+    // chain of compare-and-branch per K tile in front of every barrier cost the step 6 %: 4.29 / 4.33 vs 4.05 / 4.10 ms against the
+    // compile-time ring on one box); the kernel switches to its copy once.
+    auto main_loop = [&](auto ns_c) __attribute__((always_inline)) {
+        constexpr int NS = decltype(ns_c)::value;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            if (s < nt) issue(s, s);
+        for (int i = 0; i < nt; ++i) {
+            const int stage = i % NS;
+            const int younger = min(nt, i + NS) - (i + 1);        // tiles requested after tile i that may stay in flight
+            g_wait_younger<PIECES, NS - 1>(younger);
+            g_barrier();
+            const unsigned char* ws = smem + stage * STAGE;
+            const unsigned char* as = ws + W_BYTES;
+            if (computes && !(g.dbg & 4))
+#pragma unroll
+            for (int kk = 0; kk < G_BK / 16; ++kk) {
+                u32x4 af[MT], wf[NT];
+#pragma unroll
+                for (int a = 0; a < MT; ++a) af[a] = *reinterpret_cast<const u32x4*>(as + g_off((mw * MT + a) * 32 + ql, kk * 2 + hi));
+#pragma unroll
+                for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const u32x4*>(ws + g_off((ng * NT + j) * 32 + ql, kk * 2 + hi));
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[a][j] = GMfma<T>::run(wf[j], af[a], acc[a][j]);
+            }
+            if (i + NS < nt) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                g_barrier();
+                issue(i + NS, stage);
+            }
+        }
+    };
+    switch (g.n_stage) {
+        case 2: main_loop(std::integral_constant<int, 2>{}); break;
+        case 3: main_loop(std::integral_constant<int, 3>{}); break;
+        case 5: main_loop(std::integral_constant<int, 5>{}); break;
+        case 6: main_loop(std::integral_constant<int, 6>{}); break;
+        case 8: main_loop(std::integral_constant<int, 8>{}); break;
+        default: main_loop(std::integral_constant<int, 4>{}); break;
+    }
+
+    gemm_epilogue<T, MW, MT, NG, NT>(g, acc, smem, mw, ng, computes, n0, m0, split);
 }
 
 // sums the n_split fp32 partials in split order and writes the model dtype:  C[m][n] = sum_s part[s][m][n]

@@ -175,7 +175,10 @@ class StepEngine:
         # layer at the 7B step - every split re-reads the q rows as fp32 partials; LADE_FUSE_ROPE=1 makes it the default, the
         # in-step pass always tries both), the 128-row shape, the sqrt split rule
         self.attn_cfg = {}
-        self.attn_default = (int(os.environ.get("LADE_FUSE_ROPE", "0")) if os.environ.get("LADE_FUSE_ROPE", "0") in ("1", "2") else 0, 128, 0)
+        fuse_env = os.environ.get("LADE_FUSE_ROPE", "0")
+        if fuse_env in ("1", "2") and not cabi.experimental():
+            raise cabi.LadeHipError("LADE_FUSE_ROPE needs a library built with `make -C lookaheaddecoding_amd/csrc EXPERIMENTAL=1` (the fused forms measured slower: DESIGN 4.9)")
+        self.attn_default = (int(fuse_env) if fuse_env in ("1", "2") else 0, 128, 0)
         self.step_tune_log = {}             # row class -> what the in-step pass measured (bench.py prints it)
         self._alloc_workspaces(max_T)
         try:
@@ -661,7 +664,7 @@ class StepEngine:
         ctx = min(self.STEP_TUNE_CONTEXT, self.S_max)
         skey = (self.hidden, self.inter, self.H, self.Hkv, self.d, self.L, mclass, str(self.dtype), torch.cuda.get_device_name(self.device),
                 self.n_cu, tuple(self.kt_names), self.gu_layout, tuple(self.gemm_cfg[(n, mclass)] for n in self.LAYER_GEMMS), ctx, self.attn_default,
-                os.environ.get("LADE_ATTN_TUNE", "1"))
+                os.environ.get("LADE_ATTN_TUNE", "0"))
         with _STEP_TUNE_LOCK:
             if skey not in _STEP_TUNE_CACHE:
                 _STEP_TUNE_CACHE[skey] = self._refine_timed(mclass, T, n_probe, ctx)
@@ -718,12 +721,17 @@ class StepEngine:
         return out[:18]
 
     def _attn_candidates(self, mclass: int, T: int, S_tot: int):
-        """(fused, work-group rows, split mode) x what they resolve to at the probe context, one entry per distinct launch"""
+        """(fused, work-group rows, split mode) x what they resolve to at the probe context, one entry per distinct launch.
+        Round 6: the attention launch is FROZEN at the default (two launches, 128-row work-groups, sqrt split rule) - round 5's in-step
+        pass found every candidate within 0.2-1.5 % of it at every BASELINE shape (profiles/r5_attn_tune.txt: inside the bench's own block
+        noise), while a box-dependent choice of the split count made the 16-bit token stream and the PMC evidence box-dependent.
+        LADE_ATTN_TUNE=1 brings the coordinate back (experiments); the fused-RoPE forms are candidates only in a -DLADE_EXPERIMENTAL build."""
         inc = self.attn_cfg.get(mclass, self.attn_default)
-        if os.environ.get("LADE_ATTN_TUNE", "1") == "0":
+        if os.environ.get("LADE_ATTN_TUNE", "0") != "1":
             return [inc]
         qkv = self.gemm_cfg.get(("wqkv", mclass))
-        fuses = (2, 1, 0) if (qkv is not None and qkv[2] <= 4 and os.environ.get("LADE_FUSE_ROPE", "") != "off") else (0,)
+        fused_ok = (cabi.experimental() and qkv is not None and qkv[3] >= 0 and qkv[2] <= 4 and os.environ.get("LADE_FUSE_ROPE", "") not in ("", "off"))
+        fuses = (1, 0) if fused_ok else (0,)          # (the producer mode, fused = 2, only ever by LADE_FUSE_ROPE=2 as the default: never picked by a tuner)
         rows = (self.H // self.Hkv) * T
         shapes = [128, 64] + ([32] if rows <= 64 or self.H != self.Hkv else [])
         out, seen = [], set()

@@ -419,6 +419,20 @@ def gemm_parts(a: torch.Tensor, w: torch.Tensor, part: torch.Tensor, n_split: in
     _gemm(a, w, None, 0, ptr(part), n_split, bn, mb, mt, nt, 0, ring)
 
 
+RA_KT = 20          # K tiles a work-group of the register-resident-activation GEMM holds (gemm_decl.hpp)
+
+
+def gemm_ra_parts(a: torch.Tensor, w_kt: torch.Tensor, part: torch.Tensor, n_split: int, cs: int = 4, n_groups: int = 0) -> None:
+    """split-K GEMM with register-resident activations (M <= 128 rows, K-tile-major weight): n_split fp32 partials in `part`, bit-identical
+    to gemm_parts with the same n_split."""
+    M, K = a.shape
+    assert a.stride(1) == 1 and w_kt.dim() == 3 and w_kt.is_contiguous() and w_kt.shape[0] * 64 == K and w_kt.shape[2] == 64
+    N = w_kt.shape[1]
+    if n_split * M * N > part.numel():
+        raise cabi.LadeHipError(f"split-K workspace too small: {n_split} x {M} x {N} fp32 partials > {part.numel()}")
+    call("lade_gemm_ra_kt", ptr(a), a.stride(0), ptr(w_kt), ptr(part), M, N, K, n_split, cs, n_groups, dtype_code(a))
+
+
 def add_rmsnorm_parts(x: torch.Tensor, part: torch.Tensor, n_parts: int, w: torch.Tensor, eps: float, out: torch.Tensor) -> torch.Tensor:
     rows, hidden = x.shape
     call("lade_add_rmsnorm_parts", ptr(x), ptr(part), n_parts, rows * hidden, ptr(w), ptr(out), rows, hidden, eps, dtype_code(x))

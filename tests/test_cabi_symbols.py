@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, s), f"{s} declared in lade_hip.h but not exported"
         assert s in cabi.SIGNATURES, f"{s} has no ctypes signature"
     assert sorted(cabi.SIGNATURES) == syms
-    assert lib.lade_version() == cabi.ABI_VERSION == 2
+    assert lib.lade_version() == cabi.ABI_VERSION == 3
 
 
 def test_argument_validation_returns_error_codes_not_crashes(lib):
