@@ -62,7 +62,11 @@ using namespace lade;
 static int gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, bool ktile, void* C, int64_t ldc, float* Cpart,
                        int32_t M, int32_t N, int32_t K, int32_t n_split, int32_t bn, int32_t mb, int32_t mt, int32_t nt, int32_t ring,
                        int32_t epilogue, int32_t dtype, void* stream) {
-    LADE_REQUIRE(ring == 0 || (ring >= 2 && ring <= 8), LADE_E_ARG, "lade_gemm_skinny: ring=%d (0 = default, 2..8 stages)", ring);
+    // ring 10 / 12 / 14 / 16: the PING-PONG form of the K loop (gemm_pp.hpp: two groups of four waves alternate between multiplying a tile and
+    // requesting one) on a ring of its default depth / 2 / 4 / 6 stages
+    const bool pp = ring >= 10;
+    LADE_REQUIRE(ring == 0 || (ring >= 2 && ring <= 8) || ring == 10 || ring == 12 || ring == 14 || ring == 16, LADE_E_ARG,
+                 "lade_gemm_skinny: ring=%d (0 = default, 2..8 stages; 10 / 12 / 14 / 16 = ping-pong K loop on its default / 2 / 4 / 6 stages)", ring);
     LADE_REQUIRE(ring != 7, LADE_E_ARG, "lade_gemm_skinny: no loop is compiled for a ring of 7 stages (2, 3, 4, 5, 6, 8 are)");
     LADE_REQUIRE(epilogue == 0 || (epilogue == 1 && n_split == 1 && N % 32 == 0 && C != nullptr) || (epilogue == 2 && n_split == 1 && Cpart != nullptr), LADE_E_ARG,
                  "lade_gemm_skinny: epilogue=%d needs n_split == 1 and N %% 32 == 0 + an output matrix (1) or the pair buffer in Cpart (2)", epilogue);
@@ -71,21 +75,22 @@ static int gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, b
                  "lade_gemm_skinny: K=%d must be a multiple of %d, strides / N multiples of 8", K, G_BK);
     LADE_REQUIRE(epilogue == 2 || (n_split == 1 ? (C != nullptr && ldc % (epilogue ? 4 : 8) == 0) : (Cpart != nullptr)), LADE_E_ARG, "lade_gemm_skinny: missing output buffer");
     LADE_REQUIRE(dtype == LADE_BF16 || dtype == LADE_F16, LADE_E_DTYPE, "lade_gemm_skinny: dtype=%d", dtype);
-    if (mb == 0) mb = M <= 32 ? 1 : (M <= 64 ? 2 : (M <= 96 ? 3 : (M <= 128 ? 4 : (M <= 192 ? 6 : 8))));
-    if (mt == 0) mt = mb <= 4 ? 1 : mb / 2;
+    if (mb == 0) mb = M <= 32 ? 1 : (M <= 64 ? 2 : (M <= 96 ? 3 : (M <= 128 ? 4 : (M <= 160 ? 5 : (M <= 192 ? 6 : 8)))));
+    if (mt == 0) mt = mb <= 4 ? 1 : (mb == 5 ? 5 : mb / 2);
     if (mb > 4 && nt == 0) nt = 1;
-    LADE_REQUIRE(mb >= 1 && mb <= 8 && mt >= 1 && mt <= 4 && mb % mt == 0, LADE_E_ARG, "lade_gemm_skinny: mb=%d mt=%d", mb, mt);
-    // 192 / 256-row work-groups: the activation tile leaves room for <= 128 weight rows per stage of a 3-stage ring; the one wider
-    // shape is the double-buffered 256 x 256 tile (mb = 8, bn = 256, nt = 2 | 4)
-    if (mb > 4 && bn > 128 && !(mb == 8 && bn == 256 && (nt == 2 || nt == 4))) {
+    LADE_REQUIRE(mb >= 1 && mb <= 8 && mt >= 1 && mt <= 5 && mb % mt == 0, LADE_E_ARG, "lade_gemm_skinny: mb=%d mt=%d", mb, mt);
+    // 192 / 256-row work-groups: the activation tile leaves room for <= 128 weight rows per stage of a 3-stage ring; the wider
+    // shapes are the double-buffered 256 x 256 tile (mb = 8, bn = 256, nt = 2 | 4) and the 160-row class (mb = 5: one wave holds all five
+    // m-blocks, the eight waves - or four with two n-tiles each - lie along N: 256 weight rows + 160 activation rows = 52 KB per stage, three stages)
+    if (mb > 5 && bn > 128 && !(mb == 8 && bn == 256 && (nt == 2 || nt == 4))) {
         // (the argmax epilogue's pair buffer is indexed by the CALLER's ceil(N / bn): a silently narrower block would shift every row's pairs)
         LADE_REQUIRE(epilogue != 2, LADE_E_ARG, "lade_gemm_skinny: epilogue 2 with mb=%d needs bn <= 128 (got %d): the pair buffer's stride is ceil(N / bn)", mb, bn);
         bn = 128;
     }
     const int mw = mb / mt;
     const int tiles = bn <= 32 ? 1 : (bn <= 64 ? 2 : (bn <= 96 ? 3 : (bn <= 128 ? 4 : (bn <= 192 ? 6 : (bn <= 224 ? 7 : 8)))));      // 32-row weight tiles per work-group
-    if (nt == 0) {                                     // default: as many n-groups as waves allow
-        const int ng_max = 8 / mw;
+    if (nt == 0) {                                     // default: as many n-groups as waves allow (a ping-pong group is four waves)
+        const int ng_max = (pp ? 4 : 8) / mw > 0 ? (pp ? 4 : 8) / mw : 1;
         nt = 1;
         while (tiles / nt > ng_max || tiles % nt != 0) ++nt;
     }
@@ -97,10 +102,12 @@ static int gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, b
     g.w_ts = ktile ? (int64_t)N * G_BK : 0;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("LADE_GEMM_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
     g.epi = epilogue;
-    g.n_stage = ring;
+    g.n_stage = pp ? ring - 10 : ring;
     hipStream_t st = (hipStream_t)stream;
-    const int rc = dtype == LADE_BF16 ? gemm_dispatch_bf16(g, st, mw, mt, ng, nt) : gemm_dispatch_f16(g, st, mw, mt, ng, nt);
+    const int rc = pp ? (dtype == LADE_BF16 ? gemm_pp_dispatch_bf16(g, st, mw, mt, ng, nt) : gemm_pp_dispatch_f16(g, st, mw, mt, ng, nt))
+                      : (dtype == LADE_BF16 ? gemm_dispatch_bf16(g, st, mw, mt, ng, nt) : gemm_dispatch_f16(g, st, mw, mt, ng, nt));
     if (rc >= 0) return rc;
+    LADE_REQUIRE(!pp, LADE_E_ARG, "lade_gemm_skinny: no ping-pong kernel for mb=%d mt=%d bn=%d nt=%d (a group is a %d x %d grid of four waves)", mb, mt, bn, nt, mw, ng);
     LADE_REQUIRE(false, LADE_E_ARG, "lade_gemm_skinny: no kernel for mb=%d mt=%d bn=%d nt=%d (wave grid %d x %d)", mb, mt, bn, nt, mw, ng);
 }
 

@@ -42,5 +42,8 @@ int gemm_ra_dispatch_f16(const GemmRA& g, hipStream_t st, int mw, int cs);
 // launch the kernel built for this wave grid (mw x ng waves compute, mt x nt MFMA tiles each); -1 when it is not in the shape table
 int gemm_dispatch_bf16(const GemmK& g, hipStream_t st, int mw, int mt, int ng, int nt);
 int gemm_dispatch_f16(const GemmK& g, hipStream_t st, int mw, int mt, int ng, int nt);
+// the ping-pong form (gemm_pp.hpp): mw x ng = the grid of ONE group of four waves
+int gemm_pp_dispatch_bf16(const GemmK& g, hipStream_t st, int mw, int mt, int ng, int nt);
+int gemm_pp_dispatch_f16(const GemmK& g, hipStream_t st, int mw, int mt, int ng, int nt);
 
 }  // namespace lade

@@ -205,6 +205,7 @@ static int launch_gemm_pp(const GemmK& g0, hipStream_t st) {
     /* 64 rows */  PP_SHAPE(TT,2,1,2,1) PP_SHAPE(TT,2,1,2,2) PP_SHAPE(TT,2,1,2,3) PP_SHAPE(TT,2,1,2,4) PP_SHAPE(TT,1,2,4,1) PP_SHAPE(TT,1,2,4,2) \
     /* 96 rows */  PP_SHAPE(TT,1,3,4,1) PP_SHAPE(TT,1,3,4,2)                                                            \
     /* 128 rows */ PP_SHAPE(TT,2,2,2,1) PP_SHAPE(TT,2,2,2,2) PP_SHAPE(TT,2,2,2,3) PP_SHAPE(TT,1,4,4,1) PP_SHAPE(TT,4,1,1,4) \
+    /* 160 rows */ PP_SHAPE(TT,1,5,4,1) PP_SHAPE(TT,1,5,4,2)                                                            \
     /* 192 rows */ PP_SHAPE(TT,2,3,2,1) PP_SHAPE(TT,2,3,2,2)                                                            \
     /* 256 rows */ PP_SHAPE(TT,2,4,2,1) PP_SHAPE(TT,2,4,2,2)
 

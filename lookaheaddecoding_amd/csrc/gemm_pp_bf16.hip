@@ -1,0 +1,6 @@
+// bf16 instantiations of the ping-pong form of the skinny GEMM (see gemm_pp.hpp)
+#include "gemm_pp.hpp"
+
+namespace lade {
+int gemm_pp_dispatch_bf16(const GemmK& g, hipStream_t st, int mw, int mt, int ng, int nt) { return gemm_pp_dispatch<BF16>(g, st, mw, mt, ng, nt); }
+}  // namespace lade

@@ -101,7 +101,7 @@ _TUNE_RANKED: dict = {}
 _TUNE_LOCK = __import__("threading").Lock()
 _STEP_TUNE_CACHE: dict = {}
 _STEP_TUNE_LOCK = __import__("threading").Lock()
-REP_ROWS = {32: 30, 64: 60, 96: 92, 128: 128, 192: 180, 256: 240}        # the rows a row class is timed at
+REP_ROWS = {32: 30, 64: 60, 96: 92, 128: 128, 160: 156, 192: 180, 256: 240}        # the rows a row class is timed at
 
 
 class StepEngine:
@@ -484,6 +484,9 @@ class StepEngine:
                        (3, 3, 1, (96,))),
                   128: ((4, 1, 0, (64, 128, 192, 256)), (4, 2, 0, (128, 192, 256)), (4, 4, 0, (192, 256)), (4, 4, 2, (192, 256)), (4, 4, 1, (96,)),
                         (4, 2, 1, (96,))),
+                  # 160 rows (round 6; config 4's steps with 2..6 candidates, 132..156 rows, padded to 192 before): one wave holds all five
+                  # m-blocks (5 is prime), the waves lie along N - up to 256 weight rows beside the 20 KB activation tile, three stages
+                  160: ((5, 5, 1, (96, 128, 192, 256)), (5, 5, 2, (128, 256))),
                   # 192 / 256 rows (config 4's 120 + 6g-token steps, hot-regime steps): the activation tile alone is 24 / 32 KB per stage,
                   # so the weight tile stays at <= 128 rows for the 3-stage ring to fit the 160 KB of LDS
                   192: ((6, 3, 1, (64, 128)), (6, 3, 2, (128,)), (6, 2, 1, (64,)), (6, 2, 2, (128,))),
@@ -532,9 +535,9 @@ class StepEngine:
             # no split-K: BN weight rows x the whole K per work-group, SwiGLU in the epilogue, output in the model dtype.  Needs
             # N / BN work-groups to cover the CUs on their own: 96-row blocks at the 7B / 13B widths.
             act = torch.empty(a.shape[0], N // 2, dtype=self.dtype, device=self.device)
-            mbs = {32: 1, 64: 2, 96: 3, 128: 4, 192: 6, 256: 8}[mclass]
+            mbs = mclass // 32
             for bn in (64, 96, 128) + ((224,) if N % 224 == 0 else ()):        # 224: N = 256 x 224 at the 70B width
-                for mt in sorted({1, 2 if mbs % 2 == 0 else 1, mbs if mbs <= 4 else mbs // 2}):
+                for mt in sorted({1, 2 if mbs % 2 == 0 else 1, mbs if mbs <= 5 else mbs // 2}):
                     if mbs % mt or (mbs // mt) * (bn // 32) > 8:
                         continue
                     try:
@@ -576,7 +579,7 @@ class StepEngine:
         N / bn work-groups cover the CUs on their own at vocabulary sizes, the output is written once in the model dtype - against
         the library.  Measured at V = 32000, K = 4096, 16 rows: library 57.3 us, skinny on row-major weights 48.3 us, on the K-tile-major
         copy 39.4 us (6.65 TB/s; `profiles/r3_lm_head_probe.txt`)."""
-        mbs = {32: 1, 64: 2, 96: 3, 128: 4, 192: 6, 256: 8}[mclass]
+        mbs = mclass // 32
 
         def time_it(fn, reps=12):
             best_t = float("inf")
@@ -595,7 +598,7 @@ class StepEngine:
         t_lib = time_it(lambda: torch.matmul(a, ws_lib[0].t(), out=out))
         timed = []
         for bn in (64, 96, 128, 192, 256):
-            for mt in sorted({1, mbs if mbs <= 4 else mbs // 2}):
+            for mt in sorted({1, mbs if mbs <= 5 else mbs // 2}):
                 for nt in (0, 1, 2):
                     if mbs % mt:
                         continue
@@ -849,7 +852,8 @@ class StepEngine:
 
     LAYER_GEMMS = ("wqkv", "wo", "wgu", "wd")
     GEMM_NAMES = LAYER_GEMMS + ("lm_head",)
-    ROW_CLASSES = (32, 64, 96, 128, 192, 256)
+    # 32-row activation blocks per work-group; 160 since round 6 (a 129..160-row step padded to 192 before; LADE_ROW_CLASSES=r5: without it, A/B runs)
+    ROW_CLASSES = (32, 64, 96, 128, 192, 256) if os.environ.get("LADE_ROW_CLASSES") == "r5" else (32, 64, 96, 128, 160, 192, 256)
 
     TUNE_NAMES = GEMM_NAMES + ("attn",)        # rows of the decision table lookahead-parallel ranks exchange (parallel.encode_tune_table)
 

@@ -15,6 +15,17 @@ pytestmark = pytest.mark.gpu
 import lade_oracle as O
 
 
+def _experimental():
+    from lookaheaddecoding_amd import cabi
+    return cabi.experimental()
+
+
+# the fused forms are bit-identical but SLOWER at every BASELINE shape: since round 6 they are compiled only by
+# `make -C lookaheaddecoding_amd/csrc EXPERIMENTAL=1`; the default library refuses n_parts > 0 (test_default_build_refuses_the_fused_forms)
+needs_experimental = pytest.mark.skipif("not __import__('lookaheaddecoding_amd.cabi', fromlist=['x']).experimental()",
+                                        reason="library built without EXPERIMENTAL=1: the fused RoPE + KV append forms are not in it")
+
+
 def _tables(d, n, dtype):
     from lookaheaddecoding_amd.engine import rope_tables
     return rope_tables(d, n, 10000.0, dtype, "cuda")
@@ -84,6 +95,7 @@ def _lookahead_mask(W, N, g, P):
     return ops.StepMask.from_levels(1, ls, g * (N - 1), N - 1, P)
 
 
+@needs_experimental
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_fused_rope_equals_two_launches_mha(dtype):
     """Llama-2-7B head shape, the bench's own steps: T = 60 / 64 / 120, 2 partials, the split counts and shapes the tuner may pick"""
@@ -93,6 +105,7 @@ def test_fused_rope_equals_two_launches_mha(dtype):
         _case(32, 32, 128, m.T, P, npart, ns, wg, dtype, m, seed=P + g + ns)
 
 
+@needs_experimental
 def test_fused_rope_equals_two_launches_gqa_and_row_blocks():
     """Llama-2-70B group shape (8 heads per KV head: 480 rows = 4 row blocks at 128 rows, 8 at 64, 15 at 32 share one K / V stream and
     write the same new rows) and a 240-row MHA step (config 4 with candidates: 2 row blocks; the new rows span 4-5 tiles and two splits)"""
@@ -102,6 +115,7 @@ def test_fused_rope_equals_two_launches_gqa_and_row_blocks():
         _case(H, Hkv, 128, m.T, P, npart, ns, wg, torch.bfloat16, m, seed=H + P + ns)
 
 
+@needs_experimental
 def test_fused_rope_short_caches_and_the_deferred_request_path():
     """caches so short that a split reaches the new rows within its first ring stages: nothing may be requested before the rows are stored"""
     from lookaheaddecoding_amd import ops
@@ -112,6 +126,7 @@ def test_fused_rope_short_caches_and_the_deferred_request_path():
         _case(4, 2, 64, T, P, 2, ns, wg, torch.float16, m, seed=T + P + 1)
 
 
+@needs_experimental
 def test_fused_rope_prefill_chunks_gathered_rows_and_device_cache_length():
     """causal chunks (the tiles behind a row block's last token are neither requested nor produced by that block), cos / sin rows gathered
     per step (positions = None), cache length read from the device"""
@@ -151,6 +166,7 @@ def test_work_group_shape_is_a_launch_parameter_with_equal_results_up_to_roundin
             assert torch.allclose(out, ref, atol=2e-2, rtol=2e-2), (wg, ns, (out - ref).abs().max().item())
 
 
+@needs_experimental
 def test_fused_rope_argument_validation():
     from lookaheaddecoding_amd import cabi, ops
     m = ops.StepMask(T=8, P=64, is_prefill=True)
@@ -167,6 +183,7 @@ def test_fused_rope_argument_validation():
         ops.attn_fwd(torch.zeros(8, 256, dtype=torch.bfloat16, device="cuda"), kc, vt, m, H=2, Hkv=2, d=128, n_splits=1, wg_rows=48)
 
 
+@needs_experimental
 def test_engine_step_with_and_without_the_fused_launch_bit_identical(monkeypatch):
     """whole bf16 decoding runs at the 7B width (2 layers, attention and MLP live): token ids, step counts and the K / V rows with RoPE
     fused into the attention launch - both forms - == with the RoPE launch of its own, eager and hipGraph.  ONE engine, the form switched
@@ -210,3 +227,17 @@ def test_engine_step_with_and_without_the_fused_launch_bit_identical(monkeypatch
             bad.append((key, "K rows", sorted(set(dk[:, 2].tolist()))[:10], "layers", sorted(set(dk[:, 0].tolist())), "V columns", sorted(set(dv[:, 3].tolist()))[:10],
                         "layers", sorted(set(dv[:, 0].tolist())), "n_keep", a[3], n_keep))
     assert not bad, bad
+
+
+def test_default_build_refuses_the_fused_forms():
+    """a library built without EXPERIMENTAL=1 answers n_parts > 0 with an error code, never with a silent fallback"""
+    from lookaheaddecoding_amd import cabi, ops
+    if cabi.experimental():
+        pytest.skip("experimental build: the fused forms are present")
+    cos, sin = _tables(128, 64, torch.bfloat16)
+    kc = torch.zeros(2, 64, 128, device="cuda", dtype=torch.bfloat16)
+    vt = torch.zeros(2, 128, 64, device="cuda", dtype=torch.bfloat16)
+    parts = torch.zeros(2, 4, 6 * 128, device="cuda")
+    m = ops.StepMask(T=4, P=8, is_prefill=True)
+    with pytest.raises(cabi.LadeHipError, match="not in this build"):
+        ops.attn_fwd(None, kc, vt, m, H=2, Hkv=2, d=128, n_splits=1, qkv_parts=parts, n_parts=2, positions=None, cos=cos, sin=sin)

@@ -50,7 +50,11 @@ kts = [ops.to_ktile((torch.randn(N, K, device="cuda") * 0.02).to(DT)) for _ in r
 kz = [torch.zeros_like(k) for k in kts[:2]]
 part = torch.empty(4 * 128 * N, dtype=torch.float32, device="cuda")
 print("idle:", sample(), flush=True)
-for M, zero, kind in ((60, False, "ring"), (120, False, "ring"), (120, True, "ring"), (60, False, "ra"), (120, False, "ra"), (120, True, "ra"), (1, False, "ring")):
+CASES = ((60, False, "ring"), (120, False, "ring"), (120, True, "ring"), (60, False, "ra"), (120, False, "ra"), (120, True, "ra"), (1, False, "ring"))
+if os.environ.get("CASES"):            # CASES=76,100,120: random operands on the ring kernel at these row counts (LADE_GEMM_DBG=256: zero padding rows)
+    CASES = tuple((int(m), False, "ring") for m in os.environ["CASES"].split(","))
+    print("LADE_GEMM_DBG =", os.environ.get("LADE_GEMM_DBG", "0"))
+for M, zero, kind in CASES:
     a = torch.zeros(M, K, device="cuda", dtype=DT) if zero else torch.randn(M, K, device="cuda").to(DT)
     ws = kz if zero else kts
     act = torch.empty(M, N // 2, dtype=DT, device="cuda")
@@ -99,4 +103,5 @@ for M, zero, kind in ((60, False, "ring"), (120, False, "ring"), (120, True, "ri
     ckm = [s[2] for s in samples if s and isinstance(s[2], float)]
     print(f"gate/up 13B M={M:3d} {'zero  ' if zero else 'random'} {kind:4s}: {us:7.2f} us per launch ({N * K * 2 / 1e6 / us:4.2f} TB/s)  power {pw:6.1f} W  gfx clock mean {sum(ck) / len(ck) if ck else float('nan'):7.1f} "
           f"max {max(ckm) if ckm else float('nan'):7.1f} MHz  ({len(samples)} samples{'' if good else '; first: ' + str(samples[:1])})", flush=True)
-raw_once()
+if not os.environ.get("CASES"):
+    raw_once()
