@@ -146,6 +146,21 @@ def lib() -> C.CDLL:
     return load_library()
 
 
+def debug(name: str, default=None):
+    """One experiment switch of `LADE_DEBUG=name[=value],name2[=value2],...` (read at every call: tests flip them at run time): the kernel
+    ablation bits and tuner experiments that only tools/ and A/B runs use - gemm_dbg, attn_dbg, attn_shape, attn_splits, attn_split_rule,
+    combine_hpb (those six are read by the library itself), tune_consumer, gu_tail_fixed, tune_ring, tune_verbose, attn_tune, row_classes,
+    draw_torch, fuse_tail, fuse_rope, poll_reads_per_yield.  A bare name means "1"."""
+    s = os.environ.get("LADE_DEBUG")
+    if not s:
+        return default
+    for item in s.split(","):
+        k, _, v = item.strip().partition("=")
+        if k == name:
+            return v if v != "" else "1"
+    return default
+
+
 def experimental() -> bool:
     """whether the loaded library was built with -DLADE_EXPERIMENTAL (the attention forms with RoPE + KV append inside the launch)"""
     return bool(lib().lade_build_flags() & 1)

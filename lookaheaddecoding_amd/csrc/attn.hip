@@ -264,7 +264,7 @@ struct PlainPartials {
 
 constexpr float RESCALE_THR = 8.0f;    // log2 units: the running max is only raised when it grows by more
 
-// optional in-kernel timeline (build with -DLADE_ATTN_TIMELINE, run with LADE_ATTN_DBG=16): thread 0 of every
+// optional in-kernel timeline (build with -DLADE_ATTN_TIMELINE, run with LADE_DEBUG=attn_dbg=16): thread 0 of every
 // work-group stamps s_memtime at 7 points into the words that follow part_ml
 #ifdef LADE_ATTN_TIMELINE
 __device__ __forceinline__ void dbg_stamp(const AttnK& a, int slot) {
@@ -440,7 +440,7 @@ __device__ __forceinline__ void rope_producer(const AttnK& a, unsigned char* sme
 // four busy waves sit on four different SIMDs, and with more rows every SIMD interleaves two waves - one in its MFMA phase
 // while the other waits on LDS or runs the softmax VALU work.
 // KV split sp of n_splits takes a CONTIGUOUS range of ceil(tiles / n_splits) 64-key tiles (the interleaved assignment sp, sp+n, ...
-// is kept behind LADE_ATTN_DBG=64: it balances perfectly but loses DRAM locality, +1.6 us at the 7B shape).  The KQ key parts keep
+// is kept behind LADE_DEBUG=attn_dbg=64: it balances perfectly but loses DRAM locality, +1.6 us at the 7B shape).  The KQ key parts keep
 // separate online-softmax states and are merged through LDS at the end.
 // NPC = 0: q is read from memory and the new K / V rows are already in the cache; NPC = 2 | 4: fused RoPE + KV append from up to NPC partials
 template <typename T, int D, int RG, int KQ, int NPC>
@@ -1200,7 +1200,7 @@ static AttnK make_k(const lade_attn_args* a) {
     k.inv_T = 1.0f / (float)a->mask.T;
     k.n_groups = 0;                                 // set per work-group shape (launch_fwd_shape)
     k.scale_log2 = a->scale * 1.4426950408889634f;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("LADE_ATTN_DBG"); dbg = e ? atoi(e) : 0; } k.dbg = dbg; }
+    { static int dbg = -1; if (dbg < 0) dbg = debug_int("attn_dbg"); k.dbg = dbg; }
     k.m = a->mask;
     k.parts = a->qkv_parts; k.part_stride = (size_t)a->part_stride; k.positions = a->positions;
     k.cos_tab = (const uint16_t*)a->cos_tab; k.sin_tab = (const uint16_t*)a->sin_tab;
@@ -1231,11 +1231,11 @@ static int launch_fwd_shape(const lade_attn_args* a, hipStream_t st) {
 
 // The work-group shape is a launch parameter (lade_attn_args.wg_rows: 128 | 64 | 32 query rows of the (head-in-group, token) space per
 // work-group; 0 = 128): which one is fastest depends on the rows per KV head, the split count and the cache length, so the caller's autotune
-// decides it per launch shape inside a step, like the GEMM configurations (StepEngine._refine_attn).  LADE_ATTN_SHAPE forces one (experiments).
+// decides it per launch shape inside a step, like the GEMM configurations (StepEngine._refine_attn).  LADE_DEBUG=attn_shape=<rows> forces one (experiments).
 template <typename T, int D, int NPC>
 static int launch_fwd_npc(const lade_attn_args* a, hipStream_t st) {
     static int forced = -1;
-    if (forced < 0) { const char* e = getenv("LADE_ATTN_SHAPE"); forced = e ? atoi(e) : 0; }
+    if (forced < 0) forced = debug_int("attn_shape");
     const int shape = forced ? forced : (a->wg_rows ? a->wg_rows : 128);
     if (shape == 32) return launch_fwd_shape<T, D, 1, 4, NPC>(a, st);
     // (fused RoPE from 3 or 4 partials: two q items of four partials each + a pass of K / V rows do not fit the 128-row shape's
@@ -1293,7 +1293,7 @@ extern "C" int lade_attn_combine(const lade_attn_args* a, void* stream) {
     const AttnK k = make_k(a);
     LADE_REQUIRE(a->n_splits <= 32, LADE_E_LIMIT, "lade_attn_combine: n_splits=%d > 32", a->n_splits);
     static int hpb_env = -1;
-    if (hpb_env < 0) { const char* e = getenv("LADE_COMBINE_HPB"); hpb_env = e ? atoi(e) : 0; }
+    if (hpb_env < 0) hpb_env = debug_int("combine_hpb");
     int hpb = hpb_env > 0 ? hpb_env : 256 / (a->d / 8);     // heads per block
     while (hpb > 1 && a->H % hpb != 0) hpb >>= 1;
     dim3 grid(a->mask.T, a->H / hpb), block(a->d / 8, hpb);

@@ -1,5 +1,6 @@
 // liblade_hip.so: error channel, version and the kernel-timing helper used by bench.py.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.hpp"
@@ -24,6 +25,21 @@ int check_launch(const char* what) {
     return LADE_OK;
 }
 
+}  // namespace lade
+
+namespace lade {
+int debug_int(const char* name) {
+    const char* e = getenv("LADE_DEBUG");
+    const size_t n = strlen(name);
+    while (e && *e) {
+        while (*e == ',' || *e == ' ') ++e;
+        const char* end = strchr(e, ',');
+        const size_t len = end ? (size_t)(end - e) : strlen(e);
+        if (len >= n && strncmp(e, name, n) == 0 && (len == n || e[n] == '=')) return len == n ? 1 : atoi(e + n + 1);
+        e += len;
+    }
+    return 0;
+}
 }  // namespace lade
 
 extern "C" int lade_version(void) { return LADE_ABI_VERSION; }

@@ -11,6 +11,9 @@ namespace lade {
 // ---- host: error reporting (thread local, read through lade_last_error_string) --------
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+// one experiment switch of LADE_DEBUG=name[=value],name2[=value2],... (kernel ablation bits and forced launch shapes: tools/ only) as an int;
+// 0 when the variable or the name is absent, 1 for a bare name.  Callers cache the answer (the variable is read once per process).
+int debug_int(const char* name);
 
 #define LADE_REQUIRE(cond, code, ...)      \
     do {                                   \

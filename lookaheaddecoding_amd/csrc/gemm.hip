@@ -100,12 +100,18 @@ static int gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, b
     g.A = (const uint16_t*)A; g.W = (const uint16_t*)W; g.C = (uint16_t*)C; g.Cpart = Cpart;
     g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.n_split = n_split;
     g.w_ts = ktile ? (int64_t)N * G_BK : 0;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("LADE_GEMM_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
+    { static int dbg = -1; if (dbg < 0) dbg = debug_int("gemm_dbg"); g.dbg = dbg; }
     g.epi = epilogue;
     g.n_stage = pp ? ring - 10 : ring;
     hipStream_t st = (hipStream_t)stream;
+#ifdef LADE_EXPERIMENTAL
     const int rc = pp ? (dtype == LADE_BF16 ? gemm_pp_dispatch_bf16(g, st, mw, mt, ng, nt) : gemm_pp_dispatch_f16(g, st, mw, mt, ng, nt))
                       : (dtype == LADE_BF16 ? gemm_dispatch_bf16(g, st, mw, mt, ng, nt) : gemm_dispatch_f16(g, st, mw, mt, ng, nt));
+#else
+    // the ping-pong K loop tied or lost against the lock-step loop at every BASELINE width (profiles/r6_gemm_160_pingpong_probe.txt): built only with make EXPERIMENTAL=1
+    LADE_REQUIRE(!pp, LADE_E_ARG, "lade_gemm_skinny: the ping-pong K loop (ring=%d) is not in this build (make EXPERIMENTAL=1; lade_build_flags() bit 0)", ring);
+    const int rc = dtype == LADE_BF16 ? gemm_dispatch_bf16(g, st, mw, mt, ng, nt) : gemm_dispatch_f16(g, st, mw, mt, ng, nt);
+#endif
     if (rc >= 0) return rc;
     LADE_REQUIRE(!pp, LADE_E_ARG, "lade_gemm_skinny: no ping-pong kernel for mb=%d mt=%d bn=%d nt=%d (a group is a %d x %d grid of four waves)", mb, mt, bn, nt, mw, ng);
     LADE_REQUIRE(false, LADE_E_ARG, "lade_gemm_skinny: no kernel for mb=%d mt=%d bn=%d nt=%d (wave grid %d x %d)", mb, mt, bn, nt, mw, ng);
@@ -151,12 +157,18 @@ extern "C" int lade_gemm_ra_kt(const void* A, int64_t lda, const void* Wkt, floa
     GemmRA g;
     g.A = (const uint16_t*)A; g.W = (const uint16_t*)Wkt; g.Cpart = Cpart; g.lda = lda;
     g.M = M; g.N = N; g.K = K; g.n_split = n_split; g.tps = tps; g.n_groups = n_groups;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("LADE_GEMM_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
+    { static int dbg = -1; if (dbg < 0) dbg = debug_int("gemm_dbg"); g.dbg = dbg; }
     const int mw = (M + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
+#ifdef LADE_EXPERIMENTAL
     const int rc = dtype == LADE_BF16 ? gemm_ra_dispatch_bf16(g, st, mw, cs) : gemm_ra_dispatch_f16(g, st, mw, cs);
     if (rc >= 0) return rc;
     LADE_REQUIRE(false, LADE_E_ARG, "lade_gemm_ra_kt: no kernel for %d row blocks x %d-strip chunks", mw, cs);
+#else
+    // bit-identical to the LDS-ring kernel, 10-35 % slower at every BASELINE width (profiles/r6_gemm_ra_probe.txt): built only with make EXPERIMENTAL=1
+    (void)mw; (void)st; (void)g;
+    LADE_REQUIRE(false, LADE_E_ARG, "lade_gemm_ra_kt: the register-resident-activation kernel is not in this build (make EXPERIMENTAL=1; lade_build_flags() bit 0)");
+#endif
 }
 
 // Wkt[kt][n][0..63] = W[n][64 kt .. 64 kt + 63]: one 16-byte chunk per thread, a wave writes 1 KiB contiguous

@@ -18,7 +18,7 @@ struct GemmK {
     int64_t w_ts;          // 0: W is row-major [N][ldw];  64 N: W is K-tile-major [K/64][N][64] (elements between the K tiles of a row)
     int M, N, K, n_split;
     int n_stage;           // LDS ring depth of this launch (0: the shape's default)
-    int dbg;               // ablation switches for tools/gemm_ablate.py (LADE_GEMM_DBG): 1 = no output stores, 4 = no LDS reads / MFMA
+    int dbg;               // ablation switches for tools/gemm_ablate.py (LADE_DEBUG=gemm_dbg=<bits>): 1 = no output stores, 4 = no LDS reads / MFMA
     int epi;               // n_split == 1 only: 0 = C = A.W^T;  1 = SwiGLU over interleaved gate / up rows, C is [M][N/2];
                            // 2 = row argmax: no C, Cpart holds one (value, column) pair per row and column block
 };

@@ -61,7 +61,7 @@ template <> struct GMfma<F16> {
 // value after one rounding to the model dtype (the GEMM output, then every elementwise op, rounds like torch does)
 template <typename T> __device__ __forceinline__ float g_rnd(float f) { return to_f32<T>(from_f32<T>(f)); }
 
-// one all-zero 128-byte line: the source of the activation tile's PADDING rows (rows M .. BM-1 of the last row block) under LADE_GEMM_DBG=256
+// one all-zero 128-byte line: the source of the activation tile's PADDING rows (rows M .. BM-1 of the last row block) under LADE_DEBUG=gemm_dbg=256
 __device__ static uint32_t g_zero_line[32];
 
 // Epilogue shared by the kernels of this file: the C^T tile a work-group holds in its accumulators (wave (mw, ng) of an MW x NG grid, MT x NT MFMA
@@ -178,10 +178,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmK& g, f32x16 (&acc)[MT][
         }
     } else if (g.dbg & 32) {
         // fp32 partials straight from the accumulators: shapes whose fp32 tile does not fit the LDS (the 256 x 256 tile: the launcher sets
-        // the bit) and the experiment LADE_GEMM_DBG=32 - lane (m = ql, hi) of tile (a, j) holds the four
+        // the bit) and the experiment LADE_DEBUG=gemm_dbg=32 - lane (m = ql, hi) of tile (a, j) holds the four
         // consecutive weight rows n = 8*g4 + 4*hi .. +3 of activation row m, one 16-byte store each, no LDS staging and no barrier in
         // the tail.  Measured the same or slower than the staged whole-row stores below (7B, 60 rows: 92.9 vs 90.4-92.2 us per layer;
-        // gate/up 40.2 vs 37.5-39.2): what the partial stores cost (16 us per layer, tools/gemm_flags.py with LADE_GEMM_DBG=1) is
+        // gate/up 40.2 vs 37.5-39.2): what the partial stores cost (16 us per layer, tools/gemm_flags.py with LADE_DEBUG=gemm_dbg=1) is
         // their 48.6 MB, not the staging round trip.
         float* outp = g.Cpart + (size_t)split * g.M * g.N;
         if (computes)
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
     bool p_w[PIECES];
     bool p_z[PIECES];                                    // (per lane) this lane's row of the piece is a padding row fed from the zero line
     const bool nt_weights = !(g.dbg & 16);
-    // experiment (round 6, LADE_GEMM_DBG=256): the padding rows of the activation tile (a 120-row step fills 128, a 76-row step 96) are zeros
+    // experiment (round 6, LADE_DEBUG=gemm_dbg=256): the padding rows of the activation tile (a 120-row step fills 128, a 76-row step 96) are zeros
     // instead of copies of the last row - an MFMA on a zero operand switches far fewer gates, and at 96 / 128 rows the chip sits at its power cap
     // (profiles/r6_clock_probe.txt); the products of those rows are never stored either way
     const bool zero_pad = g.dbg & 256;
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
             unsigned char* dst = sbase + p_dst[i];
             // the weight stream is non-temporal (aux = 2): every weight byte is read by exactly one work-group, once per step, so
             // keeping it in L2 / the Infinity Cache only evicts what is re-read (activation tiles, partials).  Measured on the four
-            // 7B projections at 60 rows: 97.2 -> 92.0 us per layer, decode step 4.65 -> 4.51 ms (LADE_GEMM_DBG=16 turns it off)
+            // 7B projections at 60 rows: 97.2 -> 92.0 us per layer, decode step 4.65 -> 4.51 ms (LADE_DEBUG=gemm_dbg=16 turns it off)
             if (p_w[i] && nt_weights)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)dst, 16, 0, 2);

@@ -321,13 +321,19 @@ extern "C" int lade_kv_pack_bshd(const void* k, const void* v, int64_t tok_strid
     LADE_REQUIRE(elem_bytes == 2 || elem_bytes == 4, LADE_E_DTYPE, "lade_kv_pack_bshd: elem_bytes=%d", elem_bytes);
     LADE_REQUIRE((d * elem_bytes) % 16 == 0 && (tok_stride * elem_bytes) % 16 == 0 && (head_stride * elem_bytes) % 16 == 0 && tok_stride > 0 && head_stride > 0,
                  LADE_E_ARG, "lade_kv_pack_bshd: head rows and strides must be multiples of 16 bytes (d=%d strides %lld %lld)", d, (long long)tok_stride, (long long)head_stride);
+    // the kernel moves 16-byte vectors: a view with an odd storage offset (flash_attn_func hands over whatever the caller sliced) must not reach it
+    LADE_REQUIRE(((uintptr_t)k | (uintptr_t)v | (uintptr_t)k_cache | (uintptr_t)vt_cache) % 16 == 0 && ((int64_t)S_max * elem_bytes) % 16 == 0, LADE_E_ARG,
+                 "lade_kv_pack_bshd: k, v, k_cache, vt_cache must be 16-byte aligned (%p %p %p %p) and cache rows a multiple of 16 bytes (S_max=%d)", k, v, k_cache, vt_cache, S_max);
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)64 * (d + 16 / elem_bytes) * elem_bytes;
     const dim3 grid(cdiv(S, 64), Hkv);
     if (elem_bytes == 2) {
         hipLaunchKernelGGL(kv_pack_bshd_kernel<uint16_t>, grid, dim3(256), lds, st, (const uint16_t*)k, (const uint16_t*)v, (uint16_t*)k_cache, (uint16_t*)vt_cache, S, Hkv, d, S_max, tok_stride, head_stride);
     } else {
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kv_pack_bshd_kernel<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 64 * 1024) {
+            const hipError_t ae = hipFuncSetAttribute((const void*)kv_pack_bshd_kernel<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            LADE_REQUIRE(ae == hipSuccess, LADE_E_LIMIT, "lade_kv_pack_bshd: %zu bytes of LDS (fp32, d=%d) are more than this device grants a work-group: %s", lds, d, hipGetErrorString(ae));
+        }
         hipLaunchKernelGGL(kv_pack_bshd_kernel<uint32_t>, grid, dim3(256), lds, st, (const uint32_t*)k, (const uint32_t*)v, (uint32_t*)k_cache, (uint32_t*)vt_cache, S, Hkv, d, S_max, tok_stride, head_stride);
     }
     return check_launch("lade_kv_pack_bshd");

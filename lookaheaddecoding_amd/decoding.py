@@ -84,7 +84,7 @@ class LadeState:
         return self.record_host.tolist()
 
     POLL_TIMEOUT_S = float(os.environ.get("LADE_POLL_TIMEOUT_MS", "250")) * 1e-3
-    POLL_READS_PER_YIELD = max(1, int(os.environ.get("LADE_POLL_READS_PER_YIELD", "256")))
+    POLL_READS_PER_YIELD = max(1, int(cabi.debug("poll_reads_per_yield", "256")))
 
     def poll_record(self, step_no: int, timeout_s: Optional[float] = None) -> Optional[List[int]]:
         """The record of step `step_no` as `lade_greedy_post_step` stored it into the pinned host buffer (mapped into the device: no
@@ -108,7 +108,7 @@ class LadeState:
             time.sleep(0)                      # release the GIL: other threads of the process get to run
 
 
-DRAW_WITH_TORCH = os.environ.get("LADE_DRAW_TORCH") == "1"
+DRAW_WITH_TORCH = cabi.debug("draw_torch") == "1"
 
 
 class LookaheadDecoder:
@@ -291,13 +291,18 @@ class LookaheadDecoder:
         if rec is None:
             torch.cuda.current_stream().synchronize()
             if self.poll:
-                # the record never arrived through the mapped buffer: read the device copy, and stop polling for good - every later step
-                # would pay the same time-out.  The graphs are re-captured with the copy node instead of the mapped store.
-                rec = st.read_record()
-                self.poll = False
-                self._graph = None
-                print("[lade] the step record did not arrive through the host-mapped buffer within the polling time-out: "
-                      "falling back to stream synchronisation for this decoder", file=sys.stderr, flush=True)
+                # The spin ran out.  Two different things end here: a step that merely took longer than the time-out (the host was descheduled,
+                # a profiler attached, another process held the GPU) - its record IS in the mapped buffer now that the stream has drained,
+                # and polling stays on; or memory the device's stores do not reach coherently - the record is still absent after the
+                # synchronise: read the device copy and stop polling for good (every later step would pay the same time-out; the graphs are
+                # re-captured with the copy node instead of the mapped store).
+                rec = st.poll_record(self._step_no + 1, timeout_s=0.0)
+                if rec is None:
+                    rec = st.read_record()
+                    self.poll = False
+                    self._graph = None
+                    print("[lade] the step record did not arrive through the host-mapped buffer (absent even after the stream had drained): "
+                          "falling back to stream synchronisation for this decoder", file=sys.stderr, flush=True)
             else:
                 rec = st.record_host.tolist()
         self._step_no = rec[7]
@@ -412,7 +417,7 @@ class LookaheadDecoder:
         b = self._sampling_buffers()
         probs = ops.softmax_rows(src[row:row + 1], temperature, out=b["probs"])[0]
         if torch_gen is not None and torch_gen.device.type == "cuda":
-            if DRAW_WITH_TORCH:                   # LADE_DRAW_TORCH=1: torch.multinomial itself, input checks included (the same token, 12 launches more)
+            if DRAW_WITH_TORCH:                   # LADE_DEBUG=draw_torch: torch.multinomial itself, input checks included (the same token, 12 launches more)
                 return torch.multinomial(final_distribution(probs, struck), num_samples=1, generator=torch_gen)
             return multinomial_one(final_distribution(probs, struck), torch_gen)
         b["probs_host"].copy_(probs, non_blocking=True)

@@ -21,6 +21,7 @@ read only); wider steps (prefill chunks) and fp32 use the library on the row-maj
 """
 from __future__ import annotations
 
+import json
 import math
 import os
 import sys
@@ -172,12 +173,12 @@ class StepEngine:
         self._refining = False
         # attention launch parameters per row class: (RoPE + KV append fused into the launch, work-group rows, split mode of ops.choose_splits);
         # the default until (unless) the in-step pass decides: RoPE + append as a launch of their own (the fused form measured +3.7 us per
-        # layer at the 7B step - every split re-reads the q rows as fp32 partials; LADE_FUSE_ROPE=1 makes it the default, the
+        # layer at the 7B step - every split re-reads the q rows as fp32 partials; LADE_DEBUG=fuse_rope=1 makes it the default, the
         # in-step pass always tries both), the 128-row shape, the sqrt split rule
         self.attn_cfg = {}
-        fuse_env = os.environ.get("LADE_FUSE_ROPE", "0")
+        fuse_env = cabi.debug("fuse_rope", "0")
         if fuse_env in ("1", "2") and not cabi.experimental():
-            raise cabi.LadeHipError("LADE_FUSE_ROPE needs a library built with `make -C lookaheaddecoding_amd/csrc EXPERIMENTAL=1` (the fused forms measured slower: DESIGN 4.9)")
+            raise cabi.LadeHipError("LADE_DEBUG=fuse_rope needs a library built with `make -C lookaheaddecoding_amd/csrc EXPERIMENTAL=1` (the fused forms measured slower: DESIGN 4.9)")
         self.attn_default = (int(fuse_env) if fuse_env in ("1", "2") else 0, 128, 0)
         self.step_tune_log = {}             # row class -> what the in-step pass measured (bench.py prints it)
         self._alloc_workspaces(max_T)
@@ -185,6 +186,10 @@ class StepEngine:
             self.n_cu = torch.cuda.get_device_properties(self.device.index).multi_processor_count
         except AssertionError:      # device count not initialised on this thread yet
             self.n_cu = 256
+        self.tune_file = os.environ.get("LADE_TUNE_FILE") or None
+        self.tune_loaded = []               # row classes whose decisions came from the tune file
+        if self.tune_file and self.custom_gemm:
+            self._load_tune_file()
 
     def _fuse_gate_up(self, wg: torch.Tensor, wu: torch.Tensor) -> torch.Tensor:
         """gate and up projections as ONE weight.  16-row interleaved ([16 gate rows | their 16 up rows] per 32-row MFMA tile) so that
@@ -424,7 +429,7 @@ class StepEngine:
     def n_splits_for(self, T: int, S_tot: int, choice=None) -> int:
         if self.dtype == torch.float32:
             return 1
-        forced = int(os.environ.get("LADE_ATTN_SPLITS", "0"))        # experiments only
+        forced = int(cabi.debug("attn_splits", "0"))        # experiments only
         if forced > 0:
             return min(forced, self.max_splits, max(1, (S_tot + 63) // 64))
         # always the split + merge form, and never fewer splits than a 1024-key cache would get: the hipGraph steps are
@@ -433,6 +438,89 @@ class StepEngine:
         _fuse, wg, mode = choice if choice is not None else self.attn_choice(T)
         return min(ops.choose_splits(self.H, self.H // self.Hkv, T, max(S_tot, 1024), self.n_cu, allow_single=False,
                                      block_rows=0 if wg in (0, 128) else wg, mode=mode), self.max_splits)
+
+    # ---- persisted kernel decisions (LADE_TUNE_FILE) -----------------------------------------------------------
+    TUNE_FILE_VERSION = 1
+
+    def _tune_key(self) -> str:
+        """what a persisted decision table is valid for: the model shape, the dtype, the weight layouts the kernels stream, the GPU and the probe
+        context - NOT this engine's buffer sizes (S_max, max_T): two differently sized engines of one model share a table (the in-step probe
+        runs at a fixed context; an engine whose cache is smaller than it has its own key, as it has its own in-process decision)"""
+        return json.dumps([self.hidden, self.inter, self.H, self.Hkv, self.d, self.L, self.V, str(self.dtype), list(self.kt_names), self.gu_layout,
+                           bool(self.ktile_only), min(self.STEP_TUNE_CONTEXT, self.S_max), self._step_tunable()])
+
+    def _tune_header(self) -> dict:
+        return {"version": self.TUNE_FILE_VERSION, "abi": cabi.ABI_VERSION, "device": torch.cuda.get_device_name(self.device), "n_cu": self.n_cu,
+                "row_classes": list(self.ROW_CLASSES)}
+
+    def _load_tune_file(self) -> None:
+        """LADE_TUNE_FILE=<json>: the kernel decisions of every row class the file holds for this model are ADOPTED instead of measured - the
+        multi-second prepare() is skipped and, above all, every process (and every box) that reads the same file launches the same kernels, so
+        their 16-bit token streams are the same (a table tuned per box picks other split counts, which round differently).  A file written for
+        another GPU model, library ABI or row-class set is refused; a file without an entry for this model is extended when this engine tunes."""
+        path = self.tune_file
+        if not os.path.exists(path):
+            return
+        try:
+            with open(path) as f:
+                doc = json.load(f)
+        except Exception as e:
+            raise cabi.LadeHipError(f"LADE_TUNE_FILE={path}: unreadable ({e})")
+        hdr = self._tune_header()
+        if doc.get("header") != hdr:
+            raise cabi.LadeHipError(f"LADE_TUNE_FILE={path} was written for {doc.get('header')}, this process is {hdr}: refusing to adopt it "
+                                    f"(delete the file or point LADE_TUNE_FILE elsewhere to tune afresh)")
+        ent = doc.get("models", {}).get(self._tune_key())
+        if not ent:
+            return
+        for m_s, row in ent.items():
+            m = int(m_s)
+            if m not in self.ROW_CLASSES:
+                continue
+            for n in self.GEMM_NAMES:
+                if n in row:
+                    v = row[n]
+                    self.gemm_cfg[(n, m)] = None if v is None else tuple(int(x) for x in v)
+            if "attn" in row:
+                self.attn_cfg[m] = tuple(int(x) for x in row["attn"][:3])
+            if all(n in row for n in self.LAYER_GEMMS):
+                self._refined.add(m)
+                self.tune_loaded.append(m)
+
+    def save_tune_file(self, path: Optional[str] = None) -> Optional[str]:
+        """Writes (merges) this engine's decisions into the tune file: every row class whose four layer projections are decided (isolated pass +
+        in-step pass), + the lm_head decisions taken so far.  Atomic (temp file + rename); other models' entries are kept."""
+        path = path or self.tune_file
+        if not path or not self.custom_gemm:
+            return None
+        hdr = self._tune_header()
+        doc = {"header": hdr, "models": {}}
+        if os.path.exists(path):
+            try:
+                with open(path) as f:
+                    old = json.load(f)
+                if old.get("header") == hdr:
+                    doc = old
+            except Exception:
+                pass
+        ent = doc.setdefault("models", {}).setdefault(self._tune_key(), {})
+        for m in self.ROW_CLASSES:
+            row = ent.get(str(m), {})
+            if m in self._refined and all((n, m) in self.gemm_cfg for n in self.LAYER_GEMMS):
+                for n in self.LAYER_GEMMS:
+                    c = self.gemm_cfg[(n, m)]
+                    row[n] = None if c is None else list(c)
+                row["attn"] = list(self.attn_cfg.get(m, self.attn_default))
+            if ("lm_head", m) in self.gemm_cfg:
+                c = self.gemm_cfg[("lm_head", m)]
+                row["lm_head"] = None if c is None else list(c)
+            if row:
+                ent[str(m)] = row
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "w") as f:
+            json.dump(doc, f, indent=1, sort_keys=True)
+        os.replace(tmp, path)
+        return path
 
     # ---- GEMM selection ---------------------------------------------------------------------------
     def _tune(self, name: str, M: int):
@@ -468,6 +556,8 @@ class StepEngine:
             # what the winner took when it was timed (isolated launches, every launch on another layer's weights), for bench.py's report
             self.gemm_times[key] = (_TUNE_TIMES.get(gkey), int(N) * int(K) * ws[1][0].element_size())
         self.gemm_cfg[key] = best
+        if name == "lm_head" and self.tune_file:
+            self.save_tune_file()
         return best
 
     def _tune_timed(self, name: str, mclass: int, ws, N: int, K: int):
@@ -519,10 +609,10 @@ class StepEngine:
         # at 60 rows, ~9 us behind 2 partials of the 13B shape at 120 rows; times here are in ms)
         Mrows = a.shape[0]
         tail = (lambda out_bytes: 0.0025 + out_bytes / 4e9) if name == "wgu" else (lambda out_bytes: 0.0)
-        if name == "wgu" and os.environ.get("LADE_GU_TAIL_FIXED"):          # experiment: the flat 6 us estimate
+        if name == "wgu" and cabi.debug("gu_tail_fixed"):          # experiment: the flat 6 us estimate
             tail = lambda out_bytes: 0.006
-        if name != "wgu" and os.environ.get("LADE_TUNE_CONSUMER"):          # experiment: the consumer's read of the partials, every projection
-            rate = float(os.environ["LADE_TUNE_CONSUMER"]) * 1e9
+        if name != "wgu" and cabi.debug("tune_consumer"):          # experiment: the consumer's read of the partials, every projection
+            rate = float(cabi.debug("tune_consumer")) * 1e9
             tail = lambda out_bytes: out_bytes / rate
         # + the consumer's extra read; K-tile-only weights: the library would need its row-major operand rebuilt per call - not a candidate
         t_lib = float("inf") if ws_lib is None else time_it(lambda i: torch.matmul(a, ws_lib[i % len(ws_lib)].t(), out=out)) + 0.003 + tail(Mrows * N * 2)
@@ -548,7 +638,7 @@ class StepEngine:
         # second pass: the LDS ring depth of the best few.  More stages = more bytes in flight per work-group, fewer work-groups per CU;
         # which of the two a projection needs depends on its split count (an unsplit gate/up GEMM is one work-group per CU whatever the
         # ring costs, a 512-work-group split-K launch needs two per CU), so the depth is a per-kernel decision like the shape itself
-        if os.environ.get("LADE_TUNE_RING", "0") != "0":      # (off: isolated launches do not rank ring depths the way the step does - _refine_in_step decides them)
+        if cabi.debug("tune_ring", "0") != "0":      # (off: isolated launches do not rank ring depths the way the step does - _refine_in_step decides them)
             for t0, (mb, bn, S, mt, nt, _r) in sorted(timed)[:3]:
                 stage_bytes = (bn + 32 * mb) * 128
                 for ring in (3, 5, 6, 8):
@@ -567,7 +657,7 @@ class StepEngine:
             t_best, best = min(timed)
         self._tuned_ms = t_best
         self._tuned_ranked = sorted(timed) + ([(t_lib, None)] if ws_lib is not None else [])
-        if os.environ.get("LADE_TUNE_VERBOSE"):          # tools/gemm_tune_probe.py: what the tuner saw
+        if cabi.debug("tune_verbose"):          # tools/gemm_tune_probe.py: what the tuner saw
             mbytes = N * K * ws[0].element_size() / 1e6
             top = " ".join(f"{c}:{t * 1e3:.1f}" for t, c in sorted(timed)[:6])
             print(f"[tune] {name}:{mclass} rows={Mrows} N={N} K={K} lib {t_lib * 1e3:.1f} us | best {best} {t_best * 1e3:.1f} us "
@@ -607,7 +697,7 @@ class StepEngine:
                     except cabi.LadeHipError:
                         continue                      # wave grid not built for this row class
                     timed.append((t, (mbs, bn, 1, mt, nt, 0)))
-        if os.environ.get("LADE_TUNE_RING", "0") != "0":
+        if cabi.debug("tune_ring", "0") != "0":
             for t0, (mb, bn, S, mt, nt, _r) in sorted(timed)[:2]:
                 stage_bytes = (bn + 32 * mb) * 128
                 for ring in (3, 5, 6, 8):
@@ -622,7 +712,7 @@ class StepEngine:
         if timed and min(timed)[0] < t_lib:
             t_best, best = min(timed)
         self._tuned_ms = t_best
-        if os.environ.get("LADE_TUNE_VERBOSE"):
+        if cabi.debug("tune_verbose"):
             top = " ".join(f"{c}:{t * 1e3:.1f}" for t, c in sorted(timed)[:4])
             print(f"[tune] lm_head:{mclass} rows={a.shape[0]} N={N} K={K} lib {t_lib * 1e3:.1f} us | best {best} {t_best * 1e3:.1f} us "
                   f"({N * K * 2 / 1e6 / (t_best * 1e3):.2f} TB/s) | {top}", file=sys.stderr, flush=True)
@@ -633,7 +723,7 @@ class StepEngine:
     STEP_TUNE_MIN_BYTES = 512 << 20
     STEP_TUNE_CONTEXT = 2048             # keys of the probe step's cache: a constant, so that the decision does not depend on this engine's S_max
 
-    def _refine_in_step(self, mclass: int) -> None:
+    def _refine_in_step(self, mclass: int, allow_grow: bool = False) -> None:
         """Isolated launches do not rank GEMM configurations the way a step does: back to back on one stream a kernel meets warm caches, no
         consumer reads its split-K partials and no glue kernel sits between it and the next weight stream.  Round 4 measured it: a
         4-stage LDS ring took the 7B step from 3.91 / 3.86 to 3.78 / 3.77 ms (same box, alternating), while the isolated pass ranked 3
@@ -656,6 +746,8 @@ class StepEngine:
         n_probe = min(self.L, self.STEP_TUNE_LAYERS)
         if not self._step_tunable():
             self._refined.add(mclass)          # toy models sit in the Infinity Cache whatever runs: the isolated table stands (a property of the MODEL, not of this engine's buffers)
+            if self.tune_file:
+                self.save_tune_file()
             return
         if torch.cuda.is_current_stream_capturing():
             raise cabi.LadeHipError(f"row class {mclass}: the in-step kernel decisions are still open during a stream capture - run the step eagerly once "
@@ -663,11 +755,18 @@ class StepEngine:
         for n in self.LAYER_GEMMS:
             self._tune(n, mclass)
         if T > self.max_T:
-            self.grow(self.S_max, T)           # the probe needs T rows of workspace: a decision must not depend on how this engine was sized
+            # the probe wants REP_ROWS rows of workspace.  prepare() (construction time: nobody has captured a graph over the workspaces yet)
+            # grows them, so that a decision does not depend on how this engine was sized; a LAZY refine from inside forward() / attn_choice()
+            # must not re-allocate buffers under a caller who may hold graphs over them (grow() bumps `generation`, but only
+            # LookaheadDecoder looks at it): it probes at the rows the engine has - still rows of this class, since the triggering step is
+            if allow_grow:
+                self.grow(self.S_max, T)
+            else:
+                T = self.max_T
         ctx = min(self.STEP_TUNE_CONTEXT, self.S_max)
         skey = (self.hidden, self.inter, self.H, self.Hkv, self.d, self.L, mclass, str(self.dtype), torch.cuda.get_device_name(self.device),
                 self.n_cu, tuple(self.kt_names), self.gu_layout, tuple(self.gemm_cfg[(n, mclass)] for n in self.LAYER_GEMMS), ctx, self.attn_default,
-                os.environ.get("LADE_ATTN_TUNE", "0"))
+                cabi.debug("attn_tune", "0"))
         with _STEP_TUNE_LOCK:
             if skey not in _STEP_TUNE_CACHE:
                 _STEP_TUNE_CACHE[skey] = self._refine_timed(mclass, T, n_probe, ctx)
@@ -682,6 +781,8 @@ class StepEngine:
                 self.gemm_times[(n, mclass)] = (ranked.get(c[:5] if c else None, self.gemm_times[(n, mclass)][0]), self.gemm_times[(n, mclass)][1])
         self.step_tune_log[mclass] = log
         self._refined.add(mclass)
+        if self.tune_file:
+            self.save_tune_file()
 
     def _step_tunable(self) -> bool:
         """whether this MODEL's decisions are re-taken inside a step: its first STEP_TUNE_LAYERS layers must outweigh the Infinity Cache"""
@@ -705,7 +806,7 @@ class StepEngine:
                     continue
                 for n in self.LAYER_GEMMS:
                     self._tune(n, mclass)
-                self._refine_in_step(mclass)
+                self._refine_in_step(mclass, allow_grow=True)
 
     def _step_candidates(self, name: str, mclass: int):
         ranked = [c for _t, c in self._ranked.get((name, mclass), [])]
@@ -717,7 +818,9 @@ class StepEngine:
         for c in shapes:
             stage_bytes = (c[1] + 32 * c[0]) * 128
             dflt = min(4, 160 * 1024 // stage_bytes)
-            for ring in (0, 3, 5, 6, 8):             # (the depths the kernel is compiled for: 2, 3, 4 = default, 5, 6, 8)
+            # (the depths the kernel is compiled for: 2, 3, 4 = default, 5, 6, 8; a DOUBLE buffer only for the large stages of the 160-row
+            # class and wider - 256 weight rows + 160 activation rows: two stages beat three on 13B gate/up, 68.9 vs 71.7 us isolated)
+            for ring in (0, 3, 5, 6, 8) + ((2,) if stage_bytes >= 40 * 1024 else ()):
                 cand = c[:5] + (ring,)
                 if (ring == 0 or (ring != dflt and ring * stage_bytes <= 160 * 1024)) and cand not in out:
                     out.append(cand)
@@ -728,13 +831,13 @@ class StepEngine:
         Round 6: the attention launch is FROZEN at the default (two launches, 128-row work-groups, sqrt split rule) - round 5's in-step
         pass found every candidate within 0.2-1.5 % of it at every BASELINE shape (profiles/r5_attn_tune.txt: inside the bench's own block
         noise), while a box-dependent choice of the split count made the 16-bit token stream and the PMC evidence box-dependent.
-        LADE_ATTN_TUNE=1 brings the coordinate back (experiments); the fused-RoPE forms are candidates only in a -DLADE_EXPERIMENTAL build."""
+        LADE_DEBUG=attn_tune brings the coordinate back (experiments); the fused-RoPE forms are candidates only in a -DLADE_EXPERIMENTAL build."""
         inc = self.attn_cfg.get(mclass, self.attn_default)
-        if os.environ.get("LADE_ATTN_TUNE", "0") != "1":
+        if cabi.debug("attn_tune", "0") != "1":
             return [inc]
         qkv = self.gemm_cfg.get(("wqkv", mclass))
-        fused_ok = (cabi.experimental() and qkv is not None and qkv[3] >= 0 and qkv[2] <= 4 and os.environ.get("LADE_FUSE_ROPE", "") not in ("", "off"))
-        fuses = (1, 0) if fused_ok else (0,)          # (the producer mode, fused = 2, only ever by LADE_FUSE_ROPE=2 as the default: never picked by a tuner)
+        fused_ok = (cabi.experimental() and qkv is not None and qkv[3] >= 0 and qkv[2] <= 4 and cabi.debug("fuse_rope", "") not in ("", "off"))
+        fuses = (1, 0) if fused_ok else (0,)          # (the producer mode, fused = 2, only ever by LADE_DEBUG=fuse_rope=2 as the default: never picked by a tuner)
         rows = (self.H // self.Hkv) * T
         shapes = [128, 64] + ([32] if rows <= 64 or self.H != self.Hkv else [])
         out, seen = [], set()
@@ -807,7 +910,7 @@ class StepEngine:
                 self.gemm_cfg[(name, mclass)] = choice[name] = pick
                 log[name] = {"isolated_choice": inc, "in_step_choice": pick, "ms_per_layer_isolated_choice": round(times.get(inc, float("nan")), 5),
                              "ms_per_layer_in_step_choice": round(times[pick], 5), "candidates": len(times)}
-                if os.environ.get("LADE_TUNE_VERBOSE"):
+                if cabi.debug("tune_verbose"):
                     top = " ".join(f"{c}:{t * 1e3:.1f}" for c, t in sorted(times.items(), key=lambda kv: kv[1])[:6])
                     print(f"[tune-step] {name}:{mclass} rows={T} isolated choice {inc} {times.get(inc, float('nan')) * 1e3:.1f} us/layer -> {pick} "
                           f"{times[pick] * 1e3:.1f} | {top}", file=sys.stderr, flush=True)
@@ -829,7 +932,7 @@ class StepEngine:
                                "n_splits_at_probe": self.n_splits_for(T, P + T, choice=pick),
                                "ranked_us_per_layer": [[list(c), round(t * 1e3, 2)] for c, t in sorted(times.items(), key=lambda kv: kv[1])[:8]],
                                "fields": "(RoPE + KV append fused into the launch, work-group rows, split mode 0 sqrt | 1 fill | 2 half)"}
-                if os.environ.get("LADE_TUNE_VERBOSE"):
+                if cabi.debug("tune_verbose"):
                     top = " ".join(f"{c}:{t * 1e3:.1f}" for c, t in sorted(times.items(), key=lambda kv: kv[1])[:8])
                     print(f"[tune-step] attn:{mclass} rows={T} default {inc} {times.get(inc, float('nan')) * 1e3:.1f} us/layer -> {pick} {times[pick] * 1e3:.1f} | {top}",
                           file=sys.stderr, flush=True)
@@ -852,8 +955,8 @@ class StepEngine:
 
     LAYER_GEMMS = ("wqkv", "wo", "wgu", "wd")
     GEMM_NAMES = LAYER_GEMMS + ("lm_head",)
-    # 32-row activation blocks per work-group; 160 since round 6 (a 129..160-row step padded to 192 before; LADE_ROW_CLASSES=r5: without it, A/B runs)
-    ROW_CLASSES = (32, 64, 96, 128, 192, 256) if os.environ.get("LADE_ROW_CLASSES") == "r5" else (32, 64, 96, 128, 160, 192, 256)
+    # 32-row activation blocks per work-group; 160 since round 6 (a 129..160-row step padded to 192 before; LADE_DEBUG=row_classes=r5: without it, A/B runs)
+    ROW_CLASSES = (32, 64, 96, 128, 192, 256) if cabi.debug("row_classes") == "r5" else (32, 64, 96, 128, 160, 192, 256)
 
     TUNE_NAMES = GEMM_NAMES + ("attn",)        # rows of the decision table lookahead-parallel ranks exchange (parallel.encode_tune_table)
 
@@ -866,7 +969,7 @@ class StepEngine:
         for m in self.ROW_CLASSES:
             for n in self.GEMM_NAMES:
                 self._tune(n, m)
-            self._refine_in_step(m)
+            self._refine_in_step(m, allow_grow=True)
         out = {f"{n}:{m}": self.gemm_cfg[(n, m)] for n in self.GEMM_NAMES for m in self.ROW_CLASSES}
         out.update({f"attn:{m}": tuple(self.attn_cfg.get(m, self.attn_default)) + (0, 0, 0) for m in self.ROW_CLASSES})
         return out
@@ -916,7 +1019,7 @@ class StepEngine:
         if n_splits is None:
             n_splits = self.n_splits_for(T, P + T, choice=acfg if fused else None)
         fuse_rope = bool(acfg[0]) and cfg_qkv is not None and cfg_qkv[2] <= 4 and not self.skip_attn
-        fuse_embed = os.environ.get("LADE_FUSE_TAIL", "1") != "0"      # embedding lookup inside the first layer's input norm (one launch less)
+        fuse_embed = cabi.debug("fuse_tail", "1") != "0"      # embedding lookup inside the first layer's input norm (one launch less)
         if not (fuse_embed and self.layers):
             ops.gather_rows(self.embed, ids, out=x, rows=T)
         rpos, rcos, rsin = (pos, self.cos, self.sin) if self._ntk is None else self._ntk_rows(pos, T, P, dyn_P, rope_len, ntk_pad)
@@ -993,7 +1096,7 @@ class StepEngine:
             hn = ops.add_rmsnorm_rows(x, sel_rows, n_sel, self.norm_w, self.eps, r=r)
         cfg_lm = self._tune("lm_head", n_sel) if (self.custom_gemm and n_sel <= self.ROW_CLASSES[-1] and self.V % 8 == 0) else None
         w_lm = self._lm_kt if self._lm_kt is not None else self._lm_head
-        if cfg_lm and argmax_out is not None and n_sel <= 128 and os.environ.get("LADE_FUSE_TAIL", "1") != "0":
+        if cfg_lm and argmax_out is not None and n_sel <= 128 and cabi.debug("fuse_tail", "1") != "0":
             nb = (self.V + cfg_lm[1] - 1) // cfg_lm[1]
             pairs = torch.empty(n_sel * nb * 2, dtype=torch.float32, device=self.device)
             ops.gemm_argmax(hn, w_lm, argmax_out, pairs, bn=cfg_lm[1], mb=cfg_lm[0], mt=cfg_lm[3], nt=cfg_lm[4], ring=cfg_lm[5])

@@ -31,7 +31,9 @@ import torch
 from . import cabi, ops
 from .ops import StepMask
 
-_WS: dict = {}          # (device, dtype, Hkv, d) -> (k_cache, vt_cache) workspaces, grown in 256-key steps
+_WS: dict = {}          # (device, stream, dtype, Hkv, d) -> (k_cache, vt_cache) workspaces, grown in 256-key steps.  Keyed by the CURRENT STREAM too:
+                        # calls on one stream reuse the pair in stream order (layer after layer); calls on another stream get their own pair instead
+                        # of racing on this one
 
 
 def mask_from_lookahead(lookahead: Optional[Sequence[int]], seqlen_q: int, seqlen_k: int) -> StepMask:
@@ -60,7 +62,7 @@ def lookahead_tuple(n_input: int, level_sizes: Sequence[int], n_guess: int, kv_c
 
 def _workspace(dev: torch.device, dtype: torch.dtype, Hkv: int, d: int, S: int):
     S_max = ((S + 255) // 256) * 256
-    key = (dev, dtype, Hkv, d)
+    key = (dev, cabi.stream_ptr(), dtype, Hkv, d)
     ws = _WS.get(key)
     if ws is None or ws[0].shape[1] < S_max:
         # zero-filled once: rows past S are never visible to a query, but the last tile's V^T columns are multiplied by zero

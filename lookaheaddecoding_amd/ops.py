@@ -63,7 +63,7 @@ def choose_splits(H: int, n_rep: int, T: int, S_tot: int, n_cu: int = 256, allow
     tiles = max(1, (S_tot + 63) // 64)
     if tiles <= 5 and allow_single:               # <= 320 keys: one work-group per head beats a second (merge) launch
         return 1
-    forced = int(os.environ.get("LADE_ATTN_SPLIT_RULE", "0"))     # experiments: 1 = fill the CUs regardless of the merge cost
+    forced = int(cabi.debug("attn_split_rule", "0"))     # experiments: 1 = fill the CUs regardless of the merge cost
     fill = max(1, n_cu // max(blocks, 1))
     if forced == 1 or mode == 1:
         want = max(1, min(fill, tiles, 32))
@@ -176,7 +176,7 @@ def time_attn(q, k_cache, vt_cache, mask: StepMask, *, H, Hkv, d, n_splits: int,
     out = torch.empty(T, H * d, dtype=q.dtype, device=q.device)
     part_o = torch.empty(max(n_splits, 1), T, H, d, dtype=q.dtype, device=q.device)
     n_ml = max(n_splits, 1) * H * T * 2
-    part_ml = torch.zeros(n_ml + 16 * 4096, dtype=torch.float32, device=q.device)   # + room for LADE_ATTN_DBG=16 timestamps
+    part_ml = torch.zeros(n_ml + 16 * 4096, dtype=torch.float32, device=q.device)   # + room for LADE_DEBUG=attn_dbg=16 timestamps
     arr = (AttnArgs * len(ks))()
     for i, (k, v) in enumerate(zip(ks, vs)):
         arr[i] = AttnArgs(ptr(q), ptr(k), ptr(v), ptr(out), ptr(part_o), ptr(part_ml), None, q.stride(0), out.stride(0),

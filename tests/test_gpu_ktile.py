@@ -393,7 +393,7 @@ def test_embed_rmsnorm_is_the_row_gather_followed_by_the_norm_bit_for_bit(dtype)
 
 
 def test_step_with_the_fused_tail_gives_the_argmax_and_cache_rows_of_the_unfused_step(monkeypatch):
-    """LADE_FUSE_TAIL (default on): embedding lookup inside the first norm + argmax inside the lm_head GEMM.  One engine, the same
+    """LADE_DEBUG=fuse_tail=0 | 1 (default on): embedding lookup inside the first norm + argmax inside the lm_head GEMM.  One engine, the same
     step with the switch off and on: the same argmax ids as argmax_rows over the logits of the unfused step, the same appended K/V rows,
     for a lookahead-shaped step (31 logits rows of 60), a one-token step and a step whose logits rows span 100 rows."""
     from lookaheaddecoding_amd import ops
@@ -409,15 +409,85 @@ def test_step_with_the_fused_tail_gives_the_argmax_and_cache_rows_of_the_unfused
         sel = torch.arange(T - n_sel, T, dtype=torch.int32).cuda()
         outs = []
         for fuse in ("0", "1"):
-            monkeypatch.setenv("LADE_FUSE_TAIL", fuse)
+            monkeypatch.setenv("LADE_DEBUG", f"fuse_tail={fuse}")
             e.reset()
             e.prefill(prompt, rows=[P - 1])
             am = torch.full((n_sel,), -1, dtype=torch.int32, device="cuda")
             lg = e.forward(ids, pos, ops.StepMask(T=T, P=P, is_prefill=True), sel, n_sel, argmax_out=am)
             assert lg is None
             outs.append((am.clone(), e.k_cache(0)[:, P:P + T].clone(), e.vt_cache(cfg["layers"] - 1)[:, :, P:P + T].clone()))
-        monkeypatch.setenv("LADE_FUSE_TAIL", "0")
+        monkeypatch.setenv("LADE_DEBUG", "fuse_tail=0")
         e.reset()
         e.prefill(prompt, rows=[P - 1])
         want = ops.argmax_rows(e.forward(ids, pos, ops.StepMask(T=T, P=P, is_prefill=True), sel, n_sel))
         assert torch.equal(outs[0][0], want) and all(torch.equal(x, y) for x, y in zip(*outs)), (T, n_sel)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_160_row_class_is_bit_identical_to_the_192_row_class_on_every_shape(dtype):
+    """Round 6: a 129..160-row step runs five m-blocks per wave ((1,5,n,nt) wave grids, up to 256 weight rows per work-group) instead of
+    padding to 192 rows.  Same K slices, same MFMA chain per output element: split-K partials, the direct output (staged and - for the
+    256-row-wide tile whose fp32 staging exceeds the LDS - stored straight from the accumulators), the SwiGLU epilogue and every ring depth
+    must equal the 192-row class BIT FOR BIT; weight rows that do not fill the last work-group, row-major and K-tile-major."""
+    from lookaheaddecoding_amd import ops
+    torch.manual_seed(11)
+    shapes = ((64, 1), (96, 1), (128, 1), (192, 1), (256, 1), (128, 2), (256, 2))          # (bn, nt) -> (1,5,bn/32/nt,nt)
+    for (M, N, K) in ((129, 1000, 512), (150, 4096, 1024), (160, 776, 384), (156, 264, 256)):
+        a = torch.randn(M, K, device="cuda").to(dtype)
+        w = (torch.randn(N, K, device="cuda") * 0.05).to(dtype)
+        wk = ops.to_ktile(w)
+        ref = a.float() @ w.float().t()
+        for S in (1, 2, 4):
+            if K // 64 < 2 * S:
+                continue
+            want = ops.gemm_skinny(a, w, n_split=S, bn=128, mb=6, mt=3, nt=1)
+            p_want = None
+            if S > 1:
+                p_want = torch.empty(S * M * N, dtype=torch.float32, device="cuda")
+                ops.gemm_parts(a, w, p_want, S, 128, 6, 3, 1)
+            assert torch.allclose(want.float(), ref, atol=0.02 * K ** 0.5 * 0.05 + 0.02, rtol=2e-2)
+            for (bn, nt) in shapes:
+                for ring in (0, 2, 3):
+                    if ring * (bn + 160) * 128 > 160 * 1024:
+                        continue
+                    for wt in (w, wk):
+                        got = ops.gemm_skinny(a, wt, n_split=S, bn=bn, mb=5, mt=5, nt=nt, ring=ring)
+                        assert torch.equal(got, want), (M, N, K, S, bn, nt, ring, wt.dim())
+                    if S > 1:
+                        p = torch.full((S * M * N,), float("nan"), dtype=torch.float32, device="cuda")
+                        ops.gemm_parts(a, wk, p, S, bn, 5, 5, nt, ring)
+                        assert torch.equal(p, p_want), (M, N, K, S, bn, nt, ring)
+    # SwiGLU epilogue (unsplit gate/up) and mb = 0 (the row class by M)
+    for (M, inter, K, bn) in ((150, 1792, 1024, 96), (132, 1408, 512, 128), (160, 256, 128, 64)):
+        a = torch.randn(M, K, device="cuda").to(dtype)
+        w = ops.interleave_gate_up((torch.randn(inter, K, device="cuda") * 0.05).to(dtype), (torch.randn(inter, K, device="cuda") * 0.05).to(dtype))
+        want = ops.gemm_swiglu(a, w, torch.empty(M, inter, dtype=dtype, device="cuda"), 128 if bn != 64 else 64, 6, 3 if bn != 64 else 2, 1)
+        got = ops.gemm_swiglu(a, ops.to_ktile(w), torch.empty(M, inter, dtype=dtype, device="cuda"), bn, 5, 5, 1)
+        assert torch.equal(got, want), (M, inter, K, bn)
+        assert torch.equal(ops.gemm_skinny(a, w, bn=128), ops.gemm_skinny(a, w, bn=128, mb=5, mt=5, nt=1)), "mb = 0 picks the 160-row class for 129..160 rows"
+
+
+def test_experimental_gemm_structures_are_refused_by_the_default_build_and_correct_in_the_experimental_one():
+    """register-resident activations (lade_gemm_ra_kt) and the ping-pong K loop (ring >= 10): built by `make EXPERIMENTAL=1` only (both measured
+    slower or equal: DESIGN 4.9).  Default build: an error code, never a silent fallback.  Experimental build: RA bit-identical to the ring
+    kernel's partials, ping-pong equal to the product within fp32 summation order."""
+    from lookaheaddecoding_amd import ops
+    torch.manual_seed(12)
+    M, N, K, S = 120, 1024, 1024, 2
+    a = torch.randn(M, K, device="cuda").bfloat16()
+    wk = ops.to_ktile((torch.randn(N, K, device="cuda") * 0.05).bfloat16())
+    part = torch.empty(S * M * N, dtype=torch.float32, device="cuda")
+    if not cabi.experimental():
+        with pytest.raises(cabi.LadeHipError, match="not in this build"):
+            ops.gemm_ra_parts(a, wk, part, S, 4)
+        with pytest.raises(cabi.LadeHipError, match="not in this build"):
+            ops.gemm_parts(a, wk, part, S, 128, 4, 2, 2, ring=10)
+        return
+    want = torch.empty_like(part)
+    ops.gemm_parts(a, wk, want, S, 128, 4)
+    ops.gemm_ra_parts(a, wk, part, S, 4)
+    assert torch.equal(part, want)
+    for (bn, mt, nt) in ((128, 2, 2), (64, 2, 1), (128, 4, 1)):
+        for ring in (10, 12, 14):
+            ops.gemm_parts(a, wk, part, S, bn, 4, mt, nt, ring=ring)
+            assert torch.allclose(part.view(S, M, N).sum(0), want.view(S, M, N).sum(0), atol=1e-3, rtol=1e-4), (bn, mt, nt, ring)

@@ -7,7 +7,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from lookaheaddecoding_amd import ops
+from lookaheaddecoding_amd import cabi, ops
 
 
 def main():
@@ -48,9 +48,9 @@ def main():
             alg = 2 * (2 * a.Hkv * (P + T) * a.d + 2 * a.H * T * a.d)
             for ns in a.splits:
                 n = ns if ns > 0 else ops.choose_splits(a.H, a.H // a.Hkv, T, P + T)
-                if os.environ.get("LADE_ATTN_DBG") == "16":
+                if cabi.debug("attn_dbg") == "16":
                     us, tl = ops.time_attn(q, k, vt, mask, H=a.H, Hkv=a.Hkv, d=a.d, n_splits=n, reps=a.reps, debug_timeline=True)
-                    br = ops.attn_block_rows(a.H // a.Hkv, T) if not os.environ.get('LADE_ATTN_SHAPE') else int(os.environ['LADE_ATTN_SHAPE'])
+                    br = ops.attn_block_rows(a.H // a.Hkv, T) if not cabi.debug('attn_shape') else int(cabi.debug('attn_shape'))
                     nwg = a.Hkv * n * ((T * (a.H // a.Hkv) + br - 1) // br)
                     tl = tl[:nwg].double()
                     rel = tl[:, 1:8] - tl[:, :1]          # stamps 1..7 (7 = key-part states published, before the merge reads)

@@ -51,9 +51,9 @@ kz = [torch.zeros_like(k) for k in kts[:2]]
 part = torch.empty(4 * 128 * N, dtype=torch.float32, device="cuda")
 print("idle:", sample(), flush=True)
 CASES = ((60, False, "ring"), (120, False, "ring"), (120, True, "ring"), (60, False, "ra"), (120, False, "ra"), (120, True, "ra"), (1, False, "ring"))
-if os.environ.get("CASES"):            # CASES=76,100,120: random operands on the ring kernel at these row counts (LADE_GEMM_DBG=256: zero padding rows)
+if os.environ.get("CASES"):            # CASES=76,100,120: random operands on the ring kernel at these row counts (LADE_DEBUG=gemm_dbg=256: zero padding rows)
     CASES = tuple((int(m), False, "ring") for m in os.environ["CASES"].split(","))
-    print("LADE_GEMM_DBG =", os.environ.get("LADE_GEMM_DBG", "0"))
+    print("LADE_DEBUG =", os.environ.get("LADE_DEBUG", ""))
 for M, zero, kind in CASES:
     a = torch.zeros(M, K, device="cuda", dtype=DT) if zero else torch.randn(M, K, device="cuda").to(DT)
     ws = kz if zero else kts
@@ -64,7 +64,7 @@ for M, zero, kind in CASES:
     def run():
         i[0] = (i[0] + 1) % len(ws)
         if kind == "ring":
-            ops.gemm_swiglu(a, ws[i[0]], act, 128 if mb == 4 else 96, mb, 2 if mb == 4 else 1, 1, 3 if mb == 4 else 8)
+            ops.gemm_swiglu(a, ws[i[0]], act, 128 if mb == 4 else 96, mb, 2 if mb == 4 else (mb if mb in (3, 5) else 1), 1, 3 if mb == 4 else (8 if mb < 3 else 0))
         else:
             ops.gemm_ra_parts(a, ws[i[0]], part, 4, 4)
     for _ in range(3):

@@ -1,8 +1,9 @@
-"""Where does the skinny GEMM spend its time?  LADE_GEMM_DBG=0 | 1 (no output stores) | 4 (no LDS reads / MFMA) | 5 (loads only).
-Run on the GPU box: for d in 0 1 4 5; do LADE_GEMM_DBG=$d python tools/gemm_ablate.py; done"""
+"""Where does the skinny GEMM spend its time?  LADE_DEBUG=gemm_dbg=0 | 1 (no output stores) | 4 (no LDS reads / MFMA) | 5 (loads only).
+Run on the GPU box: for d in 0 1 4 5; do LADE_DEBUG=gemm_dbg=$d python tools/gemm_ablate.py; done"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from lookaheaddecoding_amd import cabi
 from lookaheaddecoding_amd.cabi import call, ptr, dtype_code
 def timeit(fn, reps=50):
     for _ in range(5): fn()
@@ -16,7 +17,7 @@ def timeit(fn, reps=50):
     return e0.elapsed_time(e1) * 1e3 / reps
 M = int(os.environ.get('M', '60'))
 MB = 2 if M <= 64 else 4
-dbg = os.environ.get('LADE_GEMM_DBG', '0')
+dbg = cabi.debug('gemm_dbg', '0')
 for name, N, K, cfgs in (("qkv", 12288, 4096, [(MB, 128, 5), (MB, 256, 4), (MB, 192, 4)]), ("gate_up", 22016, 4096, [(MB, 128, 4), (MB, 256, 5), (MB, 192, 2)]), ("down", 4096, 11008, [(MB, 128, 8)])):
     a = torch.randn(M, K, device="cuda").bfloat16()
     ws = [torch.randn(N, K, device="cuda").bfloat16() * 0.02 for _ in range(max(1, int(600e6 / (N * K * 2))))]

@@ -1,12 +1,13 @@
-"""A/B of kernel-level switches of the skinny GEMM (LADE_GEMM_DBG bits, read once per process) on the four 7B projections at the
+"""A/B of kernel-level switches of the skinny GEMM (LADE_DEBUG=gemm_dbg bits, read once per process) on the four 7B projections at the
 configurations the engine's autotune picks, partials left for the consumer (no reduce pass), hipGraph of dependent launches with
-rotating weights: python tools/gemm_flags.py   (run once per LADE_GEMM_DBG value)"""
+rotating weights: python tools/gemm_flags.py   (run once per LADE_DEBUG=gemm_dbg=<bits> value)"""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
+from lookaheaddecoding_amd import cabi
 from lookaheaddecoding_amd.cabi import call, dtype_code, ptr
 
 M = int(os.environ.get("M", "60"))
@@ -51,4 +52,4 @@ for name, (N, K, mb, mt, bn, nt, S) in CFG.items():
     t = timeit(mine)
     tot += t
     line.append(f"{name} {t:6.2f} us {N * K * 2 / t / 1e6:5.2f} TB/s")
-print(f"LADE_GEMM_DBG={os.environ.get('LADE_GEMM_DBG', '0'):>2s} M={M}: " + " | ".join(line) + f" | sum {tot:6.2f} us", flush=True)
+print(f"LADE_DEBUG=gemm_dbg={cabi.debug('gemm_dbg', '0'):>2s} M={M}: " + " | ".join(line) + f" | sum {tot:6.2f} us", flush=True)

@@ -1,14 +1,14 @@
 """What the activation re-reads cost the weight-streaming GEMM: the 7B / 13B step's launches with the activation traffic removed
-(LADE_GEMM_DBG bit 128: every activation piece re-reads one cached line - results are then meaningless), with and without the output
+(LADE_DEBUG=gemm_dbg bit 128: every activation piece re-reads one cached line - results are then meaningless), with and without the output
 stores (bit 1) and the LDS-read / MFMA phase (bit 4).  K-tile-major weights, every launch on another layer's weights, 40 launches per hipGraph.
-Run once per LADE_GEMM_DBG value (the env is read once per process):  for d in 0 128 1 129 5 133; do LADE_GEMM_DBG=$d python tools/gemm_ingest_probe.py; done"""
+Run once per value (the env is read once per process):  for d in 0 128 1 129 5 133; do LADE_DEBUG=gemm_dbg=$d python tools/gemm_ingest_probe.py; done"""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from lookaheaddecoding_amd import ops
+from lookaheaddecoding_amd import cabi, ops
 
 M = int(os.environ.get("M", "60"))
 MODEL = os.environ.get("MODEL", "7b")
@@ -62,4 +62,4 @@ for name, N, K, S, bn, mt, nt, ring in cfgs:
     line.append(f"{name} {t:6.2f} us ({N * K * 2 / 1e6 / t:4.2f} TB/s of W; A re-reads {n_wg * M * (K // S) * 2 / 1e6:.0f} MB over {n_wg} WGs)")
     del kts
     torch.cuda.empty_cache()
-print(f"LADE_GEMM_DBG={os.environ.get('LADE_GEMM_DBG', '0'):>3s} {MODEL} M={M}: " + " | ".join(line), flush=True)
+print(f"LADE_DEBUG=gemm_dbg={cabi.debug('gemm_dbg', '0'):>3s} {MODEL} M={M}: " + " | ".join(line), flush=True)

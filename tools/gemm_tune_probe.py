@@ -4,7 +4,7 @@ hand-written candidates (times include the tuner's consumer-tail model for gate/
 import os
 import sys
 
-os.environ["LADE_TUNE_VERBOSE"] = "1"
+os.environ["LADE_DEBUG"] = ",".join(x for x in (os.environ.get("LADE_DEBUG"), "tune_verbose") if x)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 

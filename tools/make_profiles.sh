@@ -28,5 +28,5 @@ done
 rm -rf gpurun_out/pmc
 # 4. microbenchmarks
 python tools/attn_bench.py --T 60 120 --P 128 512 1024 2048 4096 --splits 0 > $OUT/attn_sweep.txt 2>&1
-for d in 0 16; do LADE_GEMM_DBG=$d python tools/gemm_flags.py 2>&1 | tail -1; LADE_GEMM_DBG=$d M=128 python tools/gemm_flags.py 2>&1 | tail -1; done > $OUT/gemm_nt_ab.txt
+for d in 0 16; do LADE_DEBUG=gemm_dbg=$d python tools/gemm_flags.py 2>&1 | tail -1; LADE_DEBUG=gemm_dbg=$d M=128 python tools/gemm_flags.py 2>&1 | tail -1; done > $OUT/gemm_nt_ab.txt
 ls -la $OUT | head -40

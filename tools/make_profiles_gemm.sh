@@ -39,6 +39,6 @@ for w in G128 G60; do
     python tools/pmc_table.py $OUT/pmc/$w.json mfma=gpurun_out/pmc/${w}_mfma.csv lds=gpurun_out/pmc/${w}_lds.csv fetch=gpurun_out/pmc/${w}_fetch.csv write=gpurun_out/pmc/${w}_write.csv --trim $OUT/pmc/csv
 done
 rm -rf gpurun_out/pmc
-for d in 0 16; do LADE_GEMM_DBG=$d python tools/gemm_flags.py 2>&1 | tail -1; LADE_GEMM_DBG=$d M=128 python tools/gemm_flags.py 2>&1 | tail -1; done > $OUT/gemm_nt_ab.txt
-for d in 0 1 4 5; do LADE_GEMM_DBG=$d python tools/gemm_ingest_probe.py 2>&1 | tail -1; done > $OUT/gemm_ingest.txt
+for d in 0 16; do LADE_DEBUG=gemm_dbg=$d python tools/gemm_flags.py 2>&1 | tail -1; LADE_DEBUG=gemm_dbg=$d M=128 python tools/gemm_flags.py 2>&1 | tail -1; done > $OUT/gemm_nt_ab.txt
+for d in 0 1 4 5; do LADE_DEBUG=gemm_dbg=$d python tools/gemm_ingest_probe.py 2>&1 | tail -1; done > $OUT/gemm_ingest.txt
 ls -la $OUT | head -40

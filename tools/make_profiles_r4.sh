@@ -9,7 +9,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 # 1. bench lines, un-profiled: the default configuration with the CPU baseline, then the other configurations (bf16), then f16
 for c in c2 c3 c4 c5; do
-    LADE_TUNE_VERBOSE=1 timeout 1500 python bench.py --config $c --steps 32 --warmup 8 2> $OUT/bench_$c.err | grep "^{" > $OUT/bench_$c.json
+    LADE_DEBUG=tune_verbose timeout 1500 python bench.py --config $c --steps 32 --warmup 8 2> $OUT/bench_$c.err | grep "^{" > $OUT/bench_$c.json
     echo "bench $c rc=$? $(cut -c1-150 $OUT/bench_$c.json)"
 done
 for c in c2 c4; do

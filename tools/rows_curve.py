@@ -1,6 +1,6 @@
 """step(T rows) / step(1 row): the steady forward of a T-row step (causal rows over a 2048-key cache, lm_head + argmax on the last min(T, 31)
 rows) as a hipGraph on the full model, for a list of row counts - the cost that decides whether a lookahead step pays.
-    python tools/rows_curve.py 7b [rows ...]          LADE_ROW_CLASSES=r5: the row classes of rounds 1-5 (no 160-row class)"""
+    python tools/rows_curve.py 7b [rows ...]          LADE_DEBUG=row_classes=r5: the row classes of rounds 1-5 (no 160-row class)"""
 import os
 import sys
 
