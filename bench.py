@@ -1008,6 +1008,8 @@ def worker(args):
                        "parallelism": f"lp{world}" if use_lp else "single", "collective_ranks": collective_ranks, "collective": collective_kind,
                        "tokens_per_step_T": round(avg_T, 1), "kv_len_end": P_end,
                        "hipgraph": bool(dec.use_graph),
+                       "kernel_decisions": (f"decision table {os.path.relpath(eng.tune_source, ROOT)} (row classes {sorted(eng.tune_loaded)}; LADE_TUNE_FILE=off tunes on this box instead)"
+                                            if getattr(eng, "tune_source", None) else "tuned in this process (isolated pass + in-step pass)"),
                        # the second half of the metric, where the driver's parser keeps it: step compression of the timed (cold) regime, and what a
                        # lookahead step costs against the plain one-token step of the same engine - the figures that say whether lookahead decoding pays
                        "step_compression": round(S, 3),

@@ -61,9 +61,6 @@ template <> struct GMfma<F16> {
 // value after one rounding to the model dtype (the GEMM output, then every elementwise op, rounds like torch does)
 template <typename T> __device__ __forceinline__ float g_rnd(float f) { return to_f32<T>(from_f32<T>(f)); }
 
-// one all-zero 128-byte line: the source of the activation tile's PADDING rows (rows M .. BM-1 of the last row block) under LADE_DEBUG=gemm_dbg=256
-__device__ static uint32_t g_zero_line[32];
-
 // Epilogue shared by the kernels of this file: the C^T tile a work-group holds in its accumulators (wave (mw, ng) of an MW x NG grid, MT x NT MFMA
 // tiles each; lane = activation row ql of an m-tile, 16 weight rows per tile) -> row-major C / SwiGLU / row argmax / fp32 split-K partials.
 // Every wave of the work-group calls it (barriers inside); `computes` = this wave holds accumulators.
@@ -276,12 +273,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
     const uint16_t* p_src[PIECES];
     int p_dst[PIECES];
     bool p_w[PIECES];
-    bool p_z[PIECES];                                    // (per lane) this lane's row of the piece is a padding row fed from the zero line
     const bool nt_weights = !(g.dbg & 16);
-    // experiment (round 6, LADE_DEBUG=gemm_dbg=256): the padding rows of the activation tile (a 120-row step fills 128, a 76-row step 96) are zeros
-    // instead of copies of the last row - an MFMA on a zero operand switches far fewer gates, and at 96 / 128 rows the chip sits at its power cap
-    // (profiles/r6_clock_probe.txt); the products of those rows are never stored either way
-    const bool zero_pad = g.dbg & 256;
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
         const int piece = min(wave * PIECES + i, TOTAL_PIECES - 1);
@@ -292,8 +284,6 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
         p_src[i] = (isw ? g.W + (size_t)min(n0 + row, g.N - 1) * w_rs + (size_t)t0 * w_ts
                         : g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + (size_t)t0 * G_BK) + c * 8;
         if (!isw && (g.dbg & 128)) p_src[i] = g.A + (lane & 7) * 8;        // ablation (tools/gemm_ingest_probe.py): every activation piece re-reads one cached 128-byte line
-        p_z[i] = !isw && zero_pad && m0 + row >= g.M;
-        if (p_z[i]) p_src[i] = reinterpret_cast<const uint16_t*>(g_zero_line) + c * 8;
         p_dst[i] = (isw ? 0 : W_BYTES) + p * 1024;
         p_w[i] = isw;
     }
@@ -303,7 +293,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
         unsigned char* sbase = smem + stage * STAGE;
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
-            const uint16_t* src = p_src[i] + (int64_t)j * (p_w[i] ? w_ts : (((g.dbg & 128) || p_z[i]) ? (int64_t)0 : (int64_t)G_BK));
+            const uint16_t* src = p_src[i] + (int64_t)j * (p_w[i] ? w_ts : ((g.dbg & 128) ? (int64_t)0 : (int64_t)G_BK));
             unsigned char* dst = sbase + p_dst[i];
             // the weight stream is non-temporal (aux = 2): every weight byte is read by exactly one work-group, once per step, so
             // keeping it in L2 / the Infinity Cache only evicts what is re-read (activation tiles, partials).  Measured on the four

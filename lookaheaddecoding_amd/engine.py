@@ -96,6 +96,12 @@ def _on_device(fn):
     return wrapped
 
 
+def shipped_tune_table(device_name: str) -> str:
+    """path of the decision table shipped for a GPU model (it may not exist)"""
+    safe = "".join(ch if ch.isalnum() else "_" for ch in device_name).strip("_")
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", safe + ".json")
+
+
 _TUNE_CACHE: dict = {}
 _TUNE_TIMES: dict = {}
 _TUNE_RANKED: dict = {}
@@ -186,10 +192,20 @@ class StepEngine:
             self.n_cu = torch.cuda.get_device_properties(self.device.index).multi_processor_count
         except AssertionError:      # device count not initialised on this thread yet
             self.n_cu = 256
-        self.tune_file = os.environ.get("LADE_TUNE_FILE") or None
-        self.tune_loaded = []               # row classes whose decisions came from the tune file
-        if self.tune_file and self.custom_gemm:
-            self._load_tune_file()
+        # persisted kernel decisions: LADE_TUNE_FILE=<json> (read, and extended when this process tunes), else the table SHIPPED with the package
+        # for this GPU model (lookaheaddecoding_amd/tuned/<device name>.json: the BASELINE model shapes, so that every MI355X launches the same
+        # kernels for them - one 16-bit token stream per model, no multi-second tuning before the first request); LADE_TUNE_FILE=off: neither
+        env_tf = os.environ.get("LADE_TUNE_FILE") or None
+        self.tune_file = None if env_tf in (None, "off", "none", "0") else env_tf
+        self.tune_loaded = []               # row classes whose decisions came from a tune file
+        self.tune_source = None
+        if self.custom_gemm and env_tf not in ("off", "none", "0"):
+            if self.tune_file:
+                self._load_tune_file(self.tune_file, strict=True)
+            if not self.tune_loaded:
+                shipped = shipped_tune_table(torch.cuda.get_device_name(self.device))
+                if os.path.exists(shipped):
+                    self._load_tune_file(shipped, strict=False)
 
     def _fuse_gate_up(self, wg: torch.Tensor, wu: torch.Tensor) -> torch.Tensor:
         """gate and up projections as ONE weight.  16-row interleaved ([16 gate rows | their 16 up rows] per 32-row MFMA tile) so that
@@ -453,21 +469,24 @@ class StepEngine:
         return {"version": self.TUNE_FILE_VERSION, "abi": cabi.ABI_VERSION, "device": torch.cuda.get_device_name(self.device), "n_cu": self.n_cu,
                 "row_classes": list(self.ROW_CLASSES)}
 
-    def _load_tune_file(self) -> None:
+    def _load_tune_file(self, path: str, strict: bool = True) -> None:
         """LADE_TUNE_FILE=<json>: the kernel decisions of every row class the file holds for this model are ADOPTED instead of measured - the
         multi-second prepare() is skipped and, above all, every process (and every box) that reads the same file launches the same kernels, so
         their 16-bit token streams are the same (a table tuned per box picks other split counts, which round differently).  A file written for
         another GPU model, library ABI or row-class set is refused; a file without an entry for this model is extended when this engine tunes."""
-        path = self.tune_file
         if not os.path.exists(path):
             return
         try:
             with open(path) as f:
                 doc = json.load(f)
         except Exception as e:
+            if not strict:
+                return
             raise cabi.LadeHipError(f"LADE_TUNE_FILE={path}: unreadable ({e})")
         hdr = self._tune_header()
         if doc.get("header") != hdr:
+            if not strict:              # the shipped table of another library generation / GPU: ignored, this process tunes
+                return
             raise cabi.LadeHipError(f"LADE_TUNE_FILE={path} was written for {doc.get('header')}, this process is {hdr}: refusing to adopt it "
                                     f"(delete the file or point LADE_TUNE_FILE elsewhere to tune afresh)")
         ent = doc.get("models", {}).get(self._tune_key())
@@ -486,6 +505,8 @@ class StepEngine:
             if all(n in row for n in self.LAYER_GEMMS):
                 self._refined.add(m)
                 self.tune_loaded.append(m)
+        if self.tune_loaded:
+            self.tune_source = path
 
     def save_tune_file(self, path: Optional[str] = None) -> Optional[str]:
         """Writes (merges) this engine's decisions into the tune file: every row class whose four layer projections are decided (isolated pass +
@@ -819,8 +840,9 @@ class StepEngine:
             stage_bytes = (c[1] + 32 * c[0]) * 128
             dflt = min(4, 160 * 1024 // stage_bytes)
             # (the depths the kernel is compiled for: 2, 3, 4 = default, 5, 6, 8; a DOUBLE buffer only for the large stages of the 160-row
-            # class and wider - 256 weight rows + 160 activation rows: two stages beat three on 13B gate/up, 68.9 vs 71.7 us isolated)
-            for ring in (0, 3, 5, 6, 8) + ((2,) if stage_bytes >= 40 * 1024 else ()):
+            # class and wider: two stages beat three on 13B gate/up at 256 weight rows + 160 activation rows, 68.9 vs 71.7 us isolated, and
+            # the in-step pass picks them for all four projections of the 13B 192-row class, profiles/r6_rows_curve_13b.txt)
+            for ring in (0, 3, 5, 6, 8) + ((2,) if stage_bytes >= 32 * 1024 else ()):
                 cand = c[:5] + (ring,)
                 if (ring == 0 or (ring != dflt and ring * stage_bytes <= 160 * 1024)) and cand not in out:
                     out.append(cand)
