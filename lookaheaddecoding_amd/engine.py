@@ -96,10 +96,17 @@ def _on_device(fn):
     return wrapped
 
 
-def shipped_tune_table(device_name: str) -> str:
-    """path of the decision table shipped for a GPU model (it may not exist)"""
-    safe = "".join(ch if ch.isalnum() else "_" for ch in device_name).strip("_")
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", safe + ".json")
+def gpu_identity(device) -> tuple:
+    """(ISA name, CU count) - what a kernel decision is valid for.  Not the marketing name: torch reports the same MI355X as "AMD Instinct MI355X" or
+    "AMD Radeon Graphics" depending on the box's device-id table."""
+    p = torch.cuda.get_device_properties(device)
+    return str(getattr(p, "gcnArchName", "") or torch.cuda.get_device_name(device)).split(":")[0], int(p.multi_processor_count)
+
+
+def shipped_tune_table(device) -> str:
+    """path of the decision table shipped for this GPU model (it may not exist)"""
+    arch, n_cu = gpu_identity(device)
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", f"{arch}_{n_cu}cu.json")
 
 
 _TUNE_CACHE: dict = {}
@@ -193,7 +200,7 @@ class StepEngine:
         except AssertionError:      # device count not initialised on this thread yet
             self.n_cu = 256
         # persisted kernel decisions: LADE_TUNE_FILE=<json> (read, and extended when this process tunes), else the table SHIPPED with the package
-        # for this GPU model (lookaheaddecoding_amd/tuned/<device name>.json: the BASELINE model shapes, so that every MI355X launches the same
+        # for this GPU model (lookaheaddecoding_amd/tuned/<isa>_<CUs>cu.json: the BASELINE model shapes, so that every MI355X launches the same
         # kernels for them - one 16-bit token stream per model, no multi-second tuning before the first request); LADE_TUNE_FILE=off: neither
         env_tf = os.environ.get("LADE_TUNE_FILE") or None
         self.tune_file = None if env_tf in (None, "off", "none", "0") else env_tf
@@ -203,7 +210,7 @@ class StepEngine:
             if self.tune_file:
                 self._load_tune_file(self.tune_file, strict=True)
             if not self.tune_loaded:
-                shipped = shipped_tune_table(torch.cuda.get_device_name(self.device))
+                shipped = shipped_tune_table(self.device)
                 if os.path.exists(shipped):
                     self._load_tune_file(shipped, strict=False)
 
@@ -466,7 +473,7 @@ class StepEngine:
                            bool(self.ktile_only), min(self.STEP_TUNE_CONTEXT, self.S_max), self._step_tunable()])
 
     def _tune_header(self) -> dict:
-        return {"version": self.TUNE_FILE_VERSION, "abi": cabi.ABI_VERSION, "device": torch.cuda.get_device_name(self.device), "n_cu": self.n_cu,
+        return {"version": self.TUNE_FILE_VERSION, "abi": cabi.ABI_VERSION, "device": gpu_identity(self.device)[0], "n_cu": self.n_cu,
                 "row_classes": list(self.ROW_CLASSES)}
 
     def _load_tune_file(self, path: str, strict: bool = True) -> None:

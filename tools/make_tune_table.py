@@ -1,4 +1,4 @@
-"""Writes the kernel-decision table that is SHIPPED with the package for this GPU model (lookaheaddecoding_amd/tuned/<device name>.json): every
+"""Writes the kernel-decision table that is SHIPPED with the package for this GPU model (lookaheaddecoding_amd/tuned/<isa>_<CUs>cu.json): every
 row class of the BASELINE model shapes is tuned once here (isolated pass + in-step pass + lm_head), so that every MI355X launches the same
 kernels for them.  Run on the GPU box with the FINAL library build; commit the result.
     python tools/make_tune_table.py gpurun_out/tuned.json 7b:bf16 7b:f16 13b:bf16 [70b:bf16]"""
@@ -31,4 +31,4 @@ for spec in sys.argv[2:]:
         print("   ", m, {n: table.get(f"{n}:{m}") for n in eng.GEMM_NAMES}, flush=True)
     del eng
     torch.cuda.empty_cache()
-print("device:", torch.cuda.get_device_name(0), "->", os.path.basename(__import__("lookaheaddecoding_amd.engine", fromlist=["x"]).shipped_tune_table(torch.cuda.get_device_name(0))))
+print("device:", torch.cuda.get_device_name(0), "->", os.path.basename(__import__("lookaheaddecoding_amd.engine", fromlist=["x"]).shipped_tune_table(torch.device("cuda", 0))))
