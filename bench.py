@@ -1038,6 +1038,13 @@ def worker(args):
                                                  "1 / 2 / 4 / 8 ranks for the 7B shape (profiles/r4_lp_curve_7b.txt, DESIGN section 6), plus one int32 all-gather per step"))}
                           if use_lp else {}),
                        **({"shared_gpu": True, "backend": backend} if share_gpu else {})},
+            # what "identical greedy token stream" rests on, at the top level: bit-identity is PROVEN end to end on the fp32 engine (VALU attention + library
+            # GEMMs) against the reference's own traces; the 16-bit engine this line times (MFMA attention, skinny GEMMs) is pinned by the reference's own
+            # 16-bit error envelope, lookahead == plain greedy on the same kernels, and the teacher-forced check of this very run
+            "parity": {"bit_identical_to_reference": "fp32 engine only (13 greedy / 8 lookahead-parallel / 9 sampling reference traces: ids, step counts, per-step cache lengths)",
+                       "this_dtype": f"{args.dtype}: within the reference's own {args.dtype} error envelope at the BASELINE widths; lookahead == plain greedy on the same kernels (tests/test_gpu_parity_shapes.py)",
+                       "this_run_teacher_forced": None if not mid else f"{mid['greedy_check']['plain_argmax_of_own_prefix']} of {mid['greedy_check']['tokens']} mid-regime tokens are the plain step's argmax on their own prefix",
+                       "kernel_decisions_box_independent": bool(getattr(eng, "tune_source", None))},
             "step_compression": round(S, 3), "steps_per_s": round(args.steps / elapsed, 2), "spread": spread,
             "prefill": {"tokens": args.prompt_len + W + N - 3, "ms": round(prefill_s * 1e3, 2), "tokens_per_s": round((args.prompt_len + W + N - 3) / prefill_s, 1),
                         "how": f"prompt + first window level as causal chunks of <= {args.chunk} rows through the same attention / GEMM kernels, lm_head on the "

@@ -389,18 +389,23 @@ static int launch_gemm(const GemmK& g0, hipStream_t st) {
 
 // the shapes that are built: (wave grid MW x NG, MT x NT MFMA tiles per wave)
 #define SHAPE(TT, MWv, MTv, NGv, NTv) if (mw == MWv && mt == MTv && ng == NGv && nt == NTv) return launch_gemm<TT, MWv, MTv, NGv, NTv>(g, st);
-#define GO(TT)                                                                                                               \
+// four groups: each is instantiated in a translation unit of its own per dtype (gemm_part.hip compiled with -DLADE_GEMM_PART=0..3), so that the
+// ~70 shapes x 6 ring depths compile in parallel (one unit per dtype took 160 s and was the whole build)
+#define GO_0(TT)                                                                                                             \
     /* 32 rows */  SHAPE(TT,1,1,1,1) SHAPE(TT,1,1,2,1) SHAPE(TT,1,1,4,1) SHAPE(TT,1,1,8,1) SHAPE(TT,1,1,2,2) SHAPE(TT,1,1,4,2) SHAPE(TT,1,1,3,1)  \
     /* 64 rows */  SHAPE(TT,2,1,1,1) SHAPE(TT,2,1,2,1) SHAPE(TT,2,1,4,1) SHAPE(TT,2,1,3,2) SHAPE(TT,2,1,4,2) SHAPE(TT,2,1,3,1) SHAPE(TT,1,2,3,1)  \
                    SHAPE(TT,1,2,2,1) SHAPE(TT,1,2,4,1) SHAPE(TT,1,2,6,1) SHAPE(TT,1,2,8,1) SHAPE(TT,1,2,2,2) SHAPE(TT,1,2,3,2)  \
-                   SHAPE(TT,1,2,4,2) SHAPE(TT,1,2,2,3) SHAPE(TT,1,2,2,4)                                                       \
+                   SHAPE(TT,1,2,4,2) SHAPE(TT,1,2,2,3) SHAPE(TT,1,2,2,4)
+#define GO_1(TT)                                                                                                             \
     /* 96 rows */  SHAPE(TT,3,1,1,1) SHAPE(TT,3,1,2,1) SHAPE(TT,3,1,2,2) SHAPE(TT,3,1,2,3) SHAPE(TT,3,1,2,4) SHAPE(TT,1,3,3,1)  \
                    SHAPE(TT,1,3,4,1) SHAPE(TT,1,3,6,1) SHAPE(TT,1,3,8,1) SHAPE(TT,1,3,3,2) SHAPE(TT,1,3,4,2)                    \
+    /* 224-row weight blocks (N = 57344 = 256 x 224: Llama-2-70B gate/up on 256 CUs in one wave of work-groups) */        \
+                   SHAPE(TT,1,1,7,1) SHAPE(TT,1,2,7,1) SHAPE(TT,1,3,7,1) SHAPE(TT,1,4,7,1)
+#define GO_2(TT)                                                                                                             \
     /* 128 rows */ SHAPE(TT,4,1,1,1) SHAPE(TT,4,1,2,1) SHAPE(TT,4,1,2,2) SHAPE(TT,4,1,2,3) SHAPE(TT,4,1,2,4) SHAPE(TT,1,4,3,1) SHAPE(TT,2,2,3,1)  \
                    SHAPE(TT,2,2,2,1) SHAPE(TT,2,2,4,1) SHAPE(TT,2,2,3,2) SHAPE(TT,2,2,4,2) SHAPE(TT,2,2,2,2)                    \
-                   SHAPE(TT,1,4,4,1) SHAPE(TT,1,4,6,1) SHAPE(TT,1,4,8,1) SHAPE(TT,1,4,3,2) SHAPE(TT,1,4,4,2) SHAPE(TT,1,4,2,2)                    \
-    /* 224-row weight blocks (N = 57344 = 256 x 224: Llama-2-70B gate/up on 256 CUs in one wave of work-groups) */        \
-                   SHAPE(TT,1,1,7,1) SHAPE(TT,1,2,7,1) SHAPE(TT,1,3,7,1) SHAPE(TT,1,4,7,1)                                      \
+                   SHAPE(TT,1,4,4,1) SHAPE(TT,1,4,6,1) SHAPE(TT,1,4,8,1) SHAPE(TT,1,4,3,2) SHAPE(TT,1,4,4,2) SHAPE(TT,1,4,2,2)
+#define GO_3(TT)                                                                                                             \
     /* 160 rows (round 6: a 129..160-row step no longer pads to 192): ONE m-group of five m-blocks per wave, the waves along N */            \
                    SHAPE(TT,1,5,8,1) SHAPE(TT,1,5,4,2) SHAPE(TT,1,5,4,1) SHAPE(TT,1,5,2,2) SHAPE(TT,1,5,3,1) SHAPE(TT,1,5,6,1) SHAPE(TT,1,5,2,1)                    \
     /* 192 rows */ SHAPE(TT,2,3,2,1) SHAPE(TT,2,3,4,1) SHAPE(TT,2,3,2,2) SHAPE(TT,3,2,2,1) SHAPE(TT,3,2,2,2)                                     \
@@ -409,13 +414,19 @@ static int launch_gemm(const GemmK& g0, hipStream_t st) {
        per wave, 0.75 LDS fragment reads per MFMA, double-buffered 64 KB stages */                                        \
                    SHAPE(TT,2,4,4,2) SHAPE(TT,4,2,2,4)
 
-// -1: no kernel for this wave grid
-template <typename T>
-static int gemm_dispatch(const GemmK& g, hipStream_t st, int mw, int mt, int ng, int nt) {
-    GO(T)
+// -1: no kernel of this group for the wave grid
+template <typename T, int PART>
+static int gemm_dispatch_part(const GemmK& g, hipStream_t st, int mw, int mt, int ng, int nt) {
+    if constexpr (PART == 0) { GO_0(T) }
+    if constexpr (PART == 1) { GO_1(T) }
+    if constexpr (PART == 2) { GO_2(T) }
+    if constexpr (PART == 3) { GO_3(T) }
     return -1;
 }
-#undef GO
+#undef GO_0
+#undef GO_1
+#undef GO_2
+#undef GO_3
 #undef SHAPE
 
 }  // namespace lade
