@@ -109,7 +109,7 @@ def pmc_traffic(cfg, T, P, n_splits, wg_rows=128):
     attention + combine kernels.  Only reported when a profiled launch has THIS run's shape - heads, KV heads, head size, T, split
     count, and the cache length within 128 keys; returns (bytes, source file)."""
     H, Hkv, d = cfg["heads"], cfg["kv_heads"], cfg["head_dim"]
-    for name in ("r5_attn_pmc.json", "r4_attn_pmc.json", "r3_attn_pmc.json", "r2_attn_pmc.json"):
+    for name in ("r6_attn_pmc.json", "r5_attn_pmc.json", "r4_attn_pmc.json", "r3_attn_pmc.json", "r2_attn_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as f:
@@ -124,7 +124,7 @@ def pmc_traffic(cfg, T, P, n_splits, wg_rows=128):
     # rows with the NEAREST split count, corrected by what a split adds or removes - every split writes and the merge reads one partial
     # (H x T x d values of the model dtype + 2 fp32 row statistics per head row).  Said in the source string.
     best = None
-    for name in ("r5_attn_pmc.json", "r4_attn_pmc.json"):
+    for name in ("r6_attn_pmc.json", "r5_attn_pmc.json", "r4_attn_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 for e in json.load(f)["entries"]:
