@@ -25,11 +25,14 @@ def test_shipped_table_is_for_this_library_and_names_built_kernels():
     assert [4096, 11008, 32, 32, 128, 32, 32000, "torch.bfloat16"] in [k[:8] for k in keys]          # BASELINE configs 2 / 3
     assert [5120, 13824, 40, 40, 128, 40, 32016, "torch.bfloat16"] in [k[:8] for k in keys]          # config 4
     n = 0
-    for ent in doc["models"].values():
+    assert [8192, 28672, 64, 8, 128, 80, 32000, "torch.bfloat16"] in [k[:8] for k in keys]           # config 5
+    for key, ent in doc["models"].items():
+        H, Hkv = json.loads(key)[2:4]
         assert sorted(int(m) for m in ent) == sorted(StepEngine.ROW_CLASSES)
         for m, row in ent.items():
             assert set(row) >= set(StepEngine.LAYER_GEMMS) | {"attn"}
-            assert row["attn"][:3] == [0, 128, 0]                   # the attention launch is frozen
+            # the attention launch is frozen: 128-row work-groups, sqrt split rule - 64-row ones where >= 8 heads stack > 128 rows on a KV head
+            assert row["attn"][:3] == [0, 64 if (H // Hkv >= 8 and (H // Hkv) * (int(m) - 31) > 128) else 128, 0], (key, m, row["attn"])
             for name in StepEngine.GEMM_NAMES:
                 c = row.get(name)
                 if c is None:
