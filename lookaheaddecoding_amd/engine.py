@@ -496,6 +496,8 @@ class StepEngine(KernelDecisions):
                 # q and the new K / V rows straight from the qkv GEMM's partials: no RoPE launch (same bits as the two-launch form).  Mode 2:
                 # dedicated work-groups of the launch produce them once per KV head and hand them over through sync_flags
                 prod = acfg[0] == 2 and n_splits > 1
+                if prod:
+                    self.attn_flags.zero_()          # (not left to the previous launch's combine: a launch that failed would leave stale arrival counts behind)
                 ops.attn_fwd(qb if prod else None, self.k_cache(li), self.vt_cache(li), mask, H=H, Hkv=Hkv, d=d, out=o, n_splits=n_splits, part_o=self.part_o,
                              part_ml=self.part_ml, dyn_P=dyn_P, wg_rows=acfg[1], qkv_parts=part, n_parts=cfg_qkv[2], positions=rpos, cos=rcos, sin=rsin,
                              sync_flags=self.attn_flags if prod else None)
