@@ -431,7 +431,8 @@ int lade_splitk_reduce(const float* part, void* C, int64_t ldc, int32_t M, int32
 /* ---- misc ------------------------------------------------------------------------------- */
 int lade_version(void);
 /* what this build of the library contains: bit 0 = the experimental kernels (`make EXPERIMENTAL=1`): the attention forms with RoPE + KV append
- * inside the launch (lade_attn_args.n_parts > 0, sync_flags), lade_gemm_ra_kt, the ping-pong K loop of lade_gemm_skinny* (ring >= 10) - all
+ * inside the launch (lade_attn_args.n_parts > 0, sync_flags), lade_gemm_ra_kt, the ping-pong K loop of lade_gemm_skinny* (ring >= 10), its
+ * 16-row-granular tiles (mt = 16) - all
  * bit-identical or within rounding of the default forms, all measured slower or equal at every BASELINE shape; the default build answers
  * them with LADE_E_ARG */
 int lade_build_flags(void);

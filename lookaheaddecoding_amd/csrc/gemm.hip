@@ -75,6 +75,25 @@ static int gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, b
                  "lade_gemm_skinny: K=%d must be a multiple of %d, strides / N multiples of 8", K, G_BK);
     LADE_REQUIRE(epilogue == 2 || (n_split == 1 ? (C != nullptr && ldc % (epilogue ? 4 : 8) == 0) : (Cpart != nullptr)), LADE_E_ARG, "lade_gemm_skinny: missing output buffer");
     LADE_REQUIRE(dtype == LADE_BF16 || dtype == LADE_F16, LADE_E_DTYPE, "lade_gemm_skinny: dtype=%d", dtype);
+    if (mt == 16) {
+        // 16-ROW-GRANULAR tiles (gemm16.hpp; probe state: split-K partials only): mb = 16-row activation blocks of the step (5 / 7 / 9 / 11), nt = 16-row weight
+        // blocks per wave (1..4), bn = weight rows per work-group: the waves lie along N
+        LADE_REQUIRE(nt >= 1 && nt <= 4 && bn % (16 * nt) == 0 && bn / (16 * nt) <= 8 && M <= 16 * mb && N % 4 == 0, LADE_E_ARG, "lade_gemm_skinny (16-row tiles): mb=%d bn=%d nt=%d M=%d", mb, bn, nt, M);
+        GemmK g;
+        g.A = (const uint16_t*)A; g.W = (const uint16_t*)W; g.C = (uint16_t*)C; g.Cpart = Cpart;
+        g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.n_split = n_split;
+        g.w_ts = ktile ? (int64_t)N * G_BK : 0; g.dbg = 0; g.epi = epilogue; g.n_stage = ring;
+#ifdef LADE_EXPERIMENTAL
+        const int rc16 = dtype == LADE_BF16 ? gemm16_dispatch_bf16(g, (hipStream_t)stream, mb, bn / (16 * nt), nt) : gemm16_dispatch_f16(g, (hipStream_t)stream, mb, bn / (16 * nt), nt);
+        if (rc16 >= 0) return rc16;
+        LADE_REQUIRE(false, LADE_E_ARG, "lade_gemm_skinny (16-row tiles): no kernel for %d blocks x %d waves x %d tiles", mb, bn / (16 * nt), nt);
+#else
+        // 10 % fewer padded rows bought 0-4 % (13B) or nothing (7B) against the 32-row classes: the 16x16x32 tiles need more fragment reads per flop
+        // (profiles/r6_gemm16_probe.txt): built only with make EXPERIMENTAL=1
+        (void)g;
+        LADE_REQUIRE(false, LADE_E_ARG, "lade_gemm_skinny: the 16-row-granular tiles (mt=16) are not in this build (make EXPERIMENTAL=1; lade_build_flags() bit 0)");
+#endif
+    }
     if (mb == 0) mb = M <= 32 ? 1 : (M <= 64 ? 2 : (M <= 96 ? 3 : (M <= 128 ? 4 : (M <= 160 ? 5 : (M <= 192 ? 6 : 8)))));
     if (mt == 0) mt = mb <= 4 ? 1 : (mb == 5 ? 5 : mb / 2);
     if (mb > 4 && nt == 0) nt = 1;

@@ -42,6 +42,9 @@ int gemm_ra_dispatch_f16(const GemmRA& g, hipStream_t st, int mw, int cs);
 // launch the kernel built for this wave grid (mw x ng waves compute, mt x nt MFMA tiles each); -1 when it is not in the shape table
 int gemm_dispatch_bf16(const GemmK& g, hipStream_t st, int mw, int mt, int ng, int nt);
 int gemm_dispatch_f16(const GemmK& g, hipStream_t st, int mw, int mt, int ng, int nt);
+// the 16-row-granular form (gemm16.hpp): mt16 16-row activation blocks in every wave, ng waves along N with nt16 16-row weight blocks each
+int gemm16_dispatch_bf16(const GemmK& g, hipStream_t st, int mt16, int ng, int nt16);
+int gemm16_dispatch_f16(const GemmK& g, hipStream_t st, int mt16, int ng, int nt16);
 // the ping-pong form (gemm_pp.hpp): mw x ng = the grid of ONE group of four waves
 int gemm_pp_dispatch_bf16(const GemmK& g, hipStream_t st, int mw, int mt, int ng, int nt);
 int gemm_pp_dispatch_f16(const GemmK& g, hipStream_t st, int mw, int mt, int ng, int nt);

@@ -491,3 +491,24 @@ def test_experimental_gemm_structures_are_refused_by_the_default_build_and_corre
         for ring in (10, 12, 14):
             ops.gemm_parts(a, wk, part, S, bn, 4, mt, nt, ring=ring)
             assert torch.allclose(part.view(S, M, N).sum(0), want.view(S, M, N).sum(0), atol=1e-3, rtol=1e-4), (bn, mt, nt, ring)
+
+
+def test_16_row_granular_tiles_are_refused_by_the_default_build_and_correct_in_the_experimental_one():
+    """csrc/gemm16.hpp (v_mfma_f32_16x16x32 tiles, 80 / 112 / 144 / 176-row activation tiles; probe state: split-K partials): measured 0-4 % against the
+    padded 32-row classes and not integrated - the default build answers mt = 16 with an error code; the experimental build's partials sum to
+    the fp64 product (another summation order than the 32x32x16 kernel's: not bit for bit)."""
+    from lookaheaddecoding_amd import ops
+    torch.manual_seed(13)
+    for (M, N, K, S, bn, nt16) in ((76, 1024, 1024, 2, 128, 1), (138, 1536, 512, 2, 256, 2), (174, 1000, 768, 3, 128, 2), (100, 520, 384, 2, 128, 1)):
+        a = torch.randn(M, K, device="cuda").bfloat16()
+        w = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
+        part = torch.full((S * M * N,), float("nan"), dtype=torch.float32, device="cuda")
+        if not cabi.experimental():
+            with pytest.raises(cabi.LadeHipError, match="not in this build"):
+                ops.gemm_parts(a, ops.to_ktile(w), part, S, bn, (M + 15) // 16, 16, nt16)
+            return
+        for wt in (w, ops.to_ktile(w)):
+            part.fill_(float("nan"))
+            ops.gemm_parts(a, wt, part, S, bn, (M + 15) // 16, 16, nt16)
+            got = part.view(S, M, N).double().sum(0)
+            assert torch.allclose(got, a.double() @ w.double().t(), atol=2e-5, rtol=1e-5), (M, N, K, S, bn, nt16, wt.dim())
