@@ -193,6 +193,9 @@ def test_graph_buckets_follow_the_gemm_row_classes():
     for W, N, G in ((5, 3, 5), (7, 4, 7), (10, 5, 10), (5, 4, 5), (15, 5, 15), (20, 7, 20)):
         b = buckets(W, N, G)
         assert b[0] == 0 and b[-1] == G and b == sorted(set(b))
+    # round 6: the 160-row class adds a bucket where it holds more candidates than the 128-row class (config 4: 6 candidates = 156 rows)
+    classes = (32, 64, 96, 128, 160, 192, 256)
+    assert buckets(15, 5, 15) == [0, 1, 4, 9, 15] and buckets(20, 7, 20) == [0, 1, 5, 6, 12, 20]
 
 
 def test_rendezvous_ports_are_picked_below_the_ephemeral_range():
@@ -260,3 +263,38 @@ def test_multinomial_one_is_torch_multinomial():
             g1, g2 = torch.Generator().manual_seed(seed), torch.Generator().manual_seed(seed)
             assert torch.multinomial(p, 1, generator=g1).item() == multinomial_one(p, g2).item()
             assert torch.equal(g1.get_state(), g2.get_state())
+
+
+def test_lade_debug_list_is_parsed_per_call_and_by_the_library_the_same_way(monkeypatch):
+    """LADE_DEBUG=name[=value],... : ONE list for the experiment switches (round 6).  Python side read at every call; the library's own parser
+    (lade::debug_int, csrc/cabi.cpp) is not exported - its grammar is pinned here by the python twin and by the A/B tools that use both."""
+    from lookaheaddecoding_amd import cabi
+    monkeypatch.delenv("LADE_DEBUG", raising=False)
+    assert cabi.debug("gemm_dbg") is None and cabi.debug("fuse_tail", "1") == "1"
+    monkeypatch.setenv("LADE_DEBUG", "gemm_dbg=4, attn_splits=6,tune_verbose,row_classes=r5")
+    assert cabi.debug("gemm_dbg") == "4" and cabi.debug("attn_splits", "0") == "6" and cabi.debug("tune_verbose") == "1"
+    assert cabi.debug("row_classes") == "r5" and cabi.debug("gemm") is None and cabi.debug("attn_split", "x") == "x"      # no prefix matches
+    monkeypatch.setenv("LADE_DEBUG", "fuse_tail=0")
+    assert cabi.debug("fuse_tail", "1") == "0"
+
+
+def test_pmc_traffic_falls_back_to_the_nearest_profiled_split_count():
+    """bench.py's roofline.traffic (round 6): the exact profiled launch shape when profiles/ holds it, else the same shape at the nearest split count
+    corrected by one partial written + read per split and marked ESTIMATE - never null for a BASELINE shape (the round-5 driver line had 7 splits, the
+    profiles 6, and carried no traffic)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cfg = dict(heads=32, kv_heads=32, head_dim=128)
+    exact, src = bench.pmc_traffic(cfg, 60, 2219, 6, 128)
+    assert exact and "ESTIMATE" not in src and "profiles/r6_attn_pmc.json" in src
+    est, src7 = bench.pmc_traffic(cfg, 60, 2219, 7, 128)
+    per_split = 2 * (32 * 60 * 128 * 2 + 32 * 60 * 2 * 4)
+    assert src7.startswith("ESTIMATE") and est == exact + per_split
+    est5, _ = bench.pmc_traffic(cfg, 60, 2219, 5, 128)
+    assert est5 == exact - per_split
+    assert bench.pmc_traffic(cfg, 61, 2219, 6, 128) == (None, None)                   # another row count: nothing to go by
+    gqa, srcg = bench.pmc_traffic(dict(heads=64, kv_heads=8, head_dim=128), 60, 2219, 4, 64)      # the GQA launch adopted in round 6
+    assert gqa == 20659200 and "ESTIMATE" not in srcg
