@@ -20,21 +20,7 @@ N, K = 2 * INTER, HID
 DT = torch.bfloat16
 
 
-def sample():
-    """(power W, gfx clock MHz) or None"""
-    try:
-        out = subprocess.run(["amd-smi", "metric", "-g", "0", "--power", "--clock", "--json"], capture_output=True, text=True, timeout=10).stdout
-        j = json.loads(out)
-        j = j[0] if isinstance(j, list) else j.get("gpu_data", [j])[0] if isinstance(j, dict) else j
-        pw = j.get("power", {})
-        p = pw.get("socket_power", pw.get("average_socket_power", None))
-        p = p.get("value") if isinstance(p, dict) else p
-        clk = j.get("clock", {})
-        gfx = [v.get("clk", {}).get("value") if isinstance(v.get("clk"), dict) else v.get("clk") for k, v in clk.items() if k.startswith("gfx") and isinstance(v, dict)]
-        gfx = [float(x) for x in gfx if isinstance(x, (int, float))]
-        return (float(p) if p not in (None, "N/A") else None, sum(gfx) / len(gfx) if gfx else None, max(gfx) if gfx else None)
-    except Exception as e:              # noqa: BLE001 - a diagnostic tool: say what happened and go on
-        return ("ERR", repr(e)[:200], None)
+from clock_probe_lib import sample  # noqa: E402
 
 
 def raw_once():
@@ -55,6 +41,8 @@ if os.environ.get("CASES"):            # CASES=76,100,120: random operands on th
     CASES = tuple((int(m), False, "ring") for m in os.environ["CASES"].split(","))
     print("LADE_DEBUG =", os.environ.get("LADE_DEBUG", ""))
 for M, zero, kind in CASES:
+    if kind == "ra" and not __import__("lookaheaddecoding_amd.cabi", fromlist=["x"]).experimental():
+        continue                      # the RA kernel lives in the EXPERIMENTAL build only
     a = torch.zeros(M, K, device="cuda", dtype=DT) if zero else torch.randn(M, K, device="cuda").to(DT)
     ws = kz if zero else kts
     act = torch.empty(M, N // 2, dtype=DT, device="cuda")
