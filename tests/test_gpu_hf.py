@@ -150,3 +150,46 @@ def test_streamer_receives_tokens_step_by_step(hf_model, monkeypatch):
         GenerationMixin._sample = orig
         lade.decoding.FUNC_MAP.pop("_sample", None)
         lade.decoding.CONFIG_MAP.clear()
+
+
+def test_tokens_per_s_through_the_generate_surface_equals_the_engine_level_step():
+    """the surface north_star says to keep - lade.augment_all(); lade.config_lade(...); USE_LADE=1 model.generate() on a HuggingFace
+    LlamaForCausalLM - must cost what the engine-level loop costs (bench.py drives LookaheadDecoder directly; its `via_generate` leg is this measurement at
+    the full depth).  A 4-layer model of the 7B width, bf16, W=15 N=5 G=15 as in BASELINE config 2: decode ms per step through generate() against the same
+    steps on a LookaheadDecoder over a StepEngine of the same shape."""
+    import importlib.util
+    import time
+    from conftest import ROOT
+    from lookaheaddecoding_amd.decoding import LookaheadDecoder
+    from lookaheaddecoding_amd.engine import StepEngine
+    from lookaheaddecoding_amd.weights import make_config, random_weights_torch
+    spec = importlib.util.spec_from_file_location("bench_mod_gen", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cfg = make_config("llama2-7b")
+    cfg["layers"] = 4
+    W, N, G, P, new = 15, 5, 15, 512, 160
+    # engine level: the loop bench.py times
+    w = random_weights_torch(cfg, seed=0, dtype=torch.bfloat16, device="cuda")
+    eng = StepEngine(cfg, w, dtype=torch.bfloat16, device="cuda", max_seq=P + 4 * new + 256, max_T=640, consume_weights=True)
+    dec = LookaheadDecoder(eng, W, N, G, use_graph=True)
+    prompt = torch.randint(3, cfg["vocab"], (P,), generator=torch.Generator().manual_seed(123)).tolist()
+    dec.start(prompt, rng=random.Random(1))
+    for _ in range(N - 1 + 16):
+        dec.step()
+    best = float("inf")
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(48):
+            dec.step()
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / 48 * 1e3)
+    del dec, eng
+    torch.cuda.empty_cache()
+    out = bench.via_generate({}, cfg, torch.bfloat16, P, W, N, G, new, best, None)
+    assert "error" not in out, out
+    assert out["tokens"] == new and out["steps"] >= new - 4 and out["step_compression"] <= 1.05          # random weights accept (almost) nothing
+    ratio = out["surface_over_engine_step"]
+    assert 0.85 < ratio < 1.15, (ratio, out["decode_ms_per_step"], best)
+    assert out["decode_tokens_per_s"] > 2.0 * out["use_lade_0"]["decode_tokens_per_s"]                   # and transformers' own loop is far behind

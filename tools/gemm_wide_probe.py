@@ -15,7 +15,9 @@ MS = [int(x) for x in sys.argv[2:]] or [512, 847, 2304]
 HID, INTER, QKV = {"7b": (4096, 11008, 12288), "13b": (5120, 13824, 15360), "70b": (8192, 28672, 10240)}[MODEL]
 DT = torch.float16 if os.environ.get("PROBE_DTYPE") == "f16" else torch.bfloat16
 # (bn, mb, mt, nt): wave grids built for 256-row blocks (gemm_kernel.hpp)
-CANDS = [(128, 8, 4, 1), (128, 8, 4, 2), (128, 8, 2, 2), (64, 8, 4, 1), (256, 8, 4, 2), (256, 8, 2, 4)]
+CANDS = [(128, 8, 4, 1, 0), (128, 8, 4, 2, 0), (128, 8, 2, 2, 0), (64, 8, 4, 1, 0), (256, 8, 4, 2, 0), (256, 8, 2, 4, 0)]
+if cabi.experimental():          # the ping-pong K loop (csrc/gemm_pp.hpp, ring = 10 + stages) at its 256-row shapes: the compute-bound regime it was NOT measured in
+    CANDS += [(128, 8, 4, 2, 10), (128, 8, 4, 2, 12), (128, 8, 4, 2, 14), (64, 8, 4, 1, 10), (64, 8, 4, 1, 14), (64, 8, 4, 1, 16)]
 
 
 def timeit(fn, reps=12, rounds=3):
@@ -66,13 +68,13 @@ for M in MS:
         if swiglu:
             ref32 = ops.silu_mul(ref32.to(DT), layout=1).float()
         res = []
-        for (bn, mb, mt, nt) in CANDS:
+        for (bn, mb, mt, nt, ring) in CANDS:
             def run():
                 i[0] = (i[0] + 1) % n_w
                 if swiglu:
-                    ops.gemm_swiglu(a, kts[i[0]], act, bn, mb, mt, nt)
+                    ops.gemm_swiglu(a, kts[i[0]], act, bn, mb, mt, nt, ring)
                 else:
-                    ops.gemm_skinny(a, kts[i[0]], out=out, n_split=1, bn=bn, mb=mb, mt=mt, nt=nt)
+                    ops.gemm_skinny(a, kts[i[0]], out=out, n_split=1, bn=bn, mb=mb, mt=mt, nt=nt, ring=ring)
             try:
                 t = timeit(run)
             except cabi.LadeHipError as e:
@@ -82,7 +84,7 @@ for M in MS:
             got = (act if swiglu else out)
             err = (got[rs].float() - ref32).abs().max().item()
             err_lib = (ref_lib[rs].float() - ref32).abs().max().item()
-            res.append((t, (bn, mb, mt, nt), err, err_lib))
+            res.append((t, (bn, mb, mt, nt, ring), err, err_lib))
         flops = 2.0 * M * N * K
         res.sort()
         tot_lib += t_lib
