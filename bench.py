@@ -920,10 +920,10 @@ def worker(args):
                 rows.append(1 + sum(_sls([Wd - 1] + [Wd] * (Nd - 2), c0_, c1_)))
             lp_default = {"W": Wd, "N": Nd, "G": Gd, "value": round((len(run_d.tokens) - tokd) / td, 2), "unit": "tokens/s", "ms_per_step": round(td / args.steps * 1e3, 3),
                           "step_compression": round((len(run_d.tokens) - tokd) / args.steps, 3), "rows_per_rank_cold": rows, "rows_one_rank_cold": (Nd - 1) * Wd,
-                          "expected_speedup_vs_one_rank": {"2": 1.45, "4": 1.65, "8": 2.17},
-                          "expected_source": "profiles/r4_lp_curve_7b.txt (reproduced on the round-5 build: profiles/r5_lp_curve_7b.txt, 1.45 / 1.66 / 2.17): every rank's shard of the 7B shape timed on ONE GPU (forward + argmax, cold: 10.05 / 6.93 / 6.10 / 4.64 ms at "
-                                             "1 / 2 / 4 / 8 ranks), + one int32 all-gather and lade_lp_reduce_apply per step (~30-40 us); the floor is the one-token weight stream",
-                          "status": "no lookahead-parallel run on more than one physical GPU exists yet (one GPU per lease in rounds 1-5): compare the driver's numbers with `expected`",
+                          "expected_speedup_vs_one_rank": {"2": 1.44, "4": 1.74, "8": 2.11},
+                          "expected_source": "profiles/r6_lp_curve_7b.txt (rounds 4 / 5: 1.45 / 1.65-1.66 / 2.17): every rank's shard of the 7B shape timed on ONE GPU (forward + argmax, cold: 10.10 / 7.03 / 5.81 / 4.78 ms at "
+                                             "1 / 2 / 4 / 8 ranks; hot 15.14 / 10.08 / 7.09 / 5.86 = 1.50 / 2.13 / 2.58 x), + one int32 all-gather and lade_lp_reduce_apply per step (~30-40 us); the floor is the one-token weight stream",
+                          "status": "no lookahead-parallel run on more than one physical GPU exists yet (one GPU per lease in rounds 1-6; CPX partitions refused by the pool: profiles/r6_cpx_rccl.txt): compare the driver's numbers with `expected`",
                           "what": "the reference's default lookahead configuration on the same ranks, same engine, same prompt: the curve that shards"}
         except Exception as e_:                      # never at the cost of the contract's line
             lp_default = {"error": f"{type(e_).__name__}: {e_}"}
@@ -1032,10 +1032,10 @@ def worker(args):
                        **({"lp_expectation": (f"strong scaling: the {(N - 1) * W}-row step of one rank is split over the ranks (rank 0 feeds {round(avg_T, 1)} rows); "
                                               + ("at W=15 the one-rank step is already a weight stream (1.15 x the one-token step), so 1 -> 8 ranks is <= 1.15 x by "
                                                  "construction; --config lp7b / lp70b (the reference's default W=60 N=8 G=60) is the regime lookahead parallelism is built for: "
-                                                 "every rank's shard timed on one GPU gives 10.05 -> 6.93 -> 6.10 -> 4.64 ms cold at 1 / 2 / 4 / 8 ranks, 2.17 x "
-                                                 "(profiles/r4_lp_curve_7b.txt, DESIGN section 6)" if W < 40 else
-                                                 "the reference's default configuration: every rank's shard timed on one GPU gives 10.05 -> 6.93 -> 6.10 -> 4.64 ms cold at "
-                                                 "1 / 2 / 4 / 8 ranks for the 7B shape (profiles/r4_lp_curve_7b.txt, DESIGN section 6), plus one int32 all-gather per step"))}
+                                                 "every rank's shard timed on one GPU gives 10.10 -> 7.03 -> 5.81 -> 4.78 ms cold at 1 / 2 / 4 / 8 ranks, 2.11 x "
+                                                 "(profiles/r6_lp_curve_7b.txt, DESIGN section 6)" if W < 40 else
+                                                 "the reference's default configuration: every rank's shard timed on one GPU gives 10.10 -> 7.03 -> 5.81 -> 4.78 ms cold at "
+                                                 "1 / 2 / 4 / 8 ranks for the 7B shape (profiles/r6_lp_curve_7b.txt, DESIGN section 6), plus one int32 all-gather per step"))}
                           if use_lp else {}),
                        **({"shared_gpu": True, "backend": backend} if share_gpu else {})},
             # what "identical greedy token stream" rests on, at the top level: bit-identity is PROVEN end to end on the fp32 engine (VALU attention + library
