@@ -588,8 +588,8 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
     }
     const unsigned char* kbytes = reinterpret_cast<const unsigned char*>(kbase);
     const unsigned char* vbytes = reinterpret_cast<const unsigned char*>(vbase);
-    auto issue_tiles_aux = [&](int stage, int ts, int tile, auto sc1_c) {
-        constexpr int AUX = decltype(sc1_c)::value ? 16 : 0;
+    auto issue_tiles_aux = [&](int stage, int ts, int tile, auto aux_c) {
+        constexpr int AUX = decltype(aux_c)::value;          // cache-policy bits of the K / V loads: 1 = sc0, 2 = nt, 16 = sc1
         const int k0 = min(tile, last_tile) * KT;
         unsigned char* ks = smem + stage * STAGE_BYTES + ts * TILE_BYTES;
         unsigned char* vs = ks + K_BYTES;
@@ -609,9 +609,12 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
         }
     };
     int sc1_from_q = 1 << 30;            // producer mode: tiles (offsets within the split) from this one on hold rows a producer wrote in THIS launch: sc1 loads
+    // experiments (round 6, LADE_DEBUG=attn_dbg=128 | 256): the K / V stream with sc1 (past the CU's L1) / nt + sc1, as the GEMMs' weight stream (work-group uniform)
+    const int kv_policy = (a.dbg & 128) ? 1 : ((a.dbg & 256) ? 2 : 0);
     auto issue_tiles = [&](int stage, int ts, int tile) {
-        if (NPC > 0 && tile - base >= sc1_from_q) issue_tiles_aux(stage, ts, tile, std::true_type{});
-        else issue_tiles_aux(stage, ts, tile, std::false_type{});
+        if ((NPC > 0 && tile - base >= sc1_from_q) || kv_policy == 1) issue_tiles_aux(stage, ts, tile, std::integral_constant<int, 16>{});
+        else if (kv_policy == 2) issue_tiles_aux(stage, ts, tile, std::integral_constant<int, 18>{});
+        else issue_tiles_aux(stage, ts, tile, std::integral_constant<int, 0>{});
     };
     const int nt = (my_tiles + TPS - 1) / TPS;                                  // stages
     const int nt_issued = max(nt, NSTG);                                        // the first NSTG stages are always in flight

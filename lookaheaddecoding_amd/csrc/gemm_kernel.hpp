@@ -295,10 +295,15 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
         for (int i = 0; i < PIECES; ++i) {
             const uint16_t* src = p_src[i] + (int64_t)j * (p_w[i] ? w_ts : ((g.dbg & 128) ? (int64_t)0 : (int64_t)G_BK));
             unsigned char* dst = sbase + p_dst[i];
-            // the weight stream is non-temporal (aux = 2): every weight byte is read by exactly one work-group, once per step, so
-            // keeping it in L2 / the Infinity Cache only evicts what is re-read (activation tiles, partials).  Measured on the four
-            // 7B projections at 60 rows: 97.2 -> 92.0 us per layer, decode step 4.65 -> 4.51 ms (LADE_DEBUG=gemm_dbg=16 turns it off)
-            if (p_w[i] && nt_weights)
+            // cache policy of the weight stream (bits: 1 = sc0, 2 = nt, 16 = sc1): NON-TEMPORAL (round 2) - every weight byte is read by exactly one
+            // work-group, once per step, so keeping it in L2 / the Infinity Cache only evicts what is re-read (activation tiles, partials): 97.2 -> 92.0 us
+            // per 7B layer at 60 rows, decode step 4.65 -> 4.51 ms (LADE_DEBUG=gemm_dbg=16 turns it off).  nt + sc1 (round 6, gemm_dbg=256) wins 7-17 % on
+            // ISOLATED back-to-back launches and LOSES 4-7 % in the step (c2 4.20 vs 3.93 ms, c4 8.53 vs 8.15, every row count of the rows curve:
+            // profiles/r6_weight_cache_policy_*.txt) - one more case of isolated launches not ranking like the step.
+            if (p_w[i] && (g.dbg & 256))
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 18);
+            else if (p_w[i] && nt_weights)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)dst, 16, 0, 2);
             else
