@@ -24,6 +24,16 @@
 
 #include "common.hpp"
 
+// Cache policy of the K / V stream (bits 1 = sc0, 2 = nt, 16 = sc1), a COMPILE-time constant: NON-TEMPORAL + sc1 since round 6.  The cache of a 2 k-token sequence
+// is 1 GB per 7B model - far beyond L2 and the Infinity Cache - and every step reads all of it once: at the default policy it only evicts what IS re-read
+// (activation tiles, split-K partials, the attention partials the merge reads next).  One library per arm, alternating on one box, the shipped decision table
+// in every arm (profiles/r6_cache_policy_variants_ab.txt): attention pair 16.3-16.5 vs 17.4-17.9 us at config 2 (0.283-0.286 vs 0.261-0.268 of 8 TB/s), 22.1-22.7
+// vs 23.3-23.9 at config 4; plain decoding 3.27 vs 3.35 ms (7B), 5.41 vs 5.48 (13B); config 2 mid / hot regimes -1.5 %; the cold 60 / 120-row steps equal within
+// the noise.  Variants: tools/build_variant.sh NAME "-DLADE_KV_AUX=0" (a run-time switch in the issue path would cost more than the policy gives).
+#ifndef LADE_KV_AUX
+#define LADE_KV_AUX 18
+#endif
+
 namespace lade {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -609,12 +619,10 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
         }
     };
     int sc1_from_q = 1 << 30;            // producer mode: tiles (offsets within the split) from this one on hold rows a producer wrote in THIS launch: sc1 loads
-    // experiments (round 6, LADE_DEBUG=attn_dbg=128 | 256): the K / V stream with sc1 (past the CU's L1) / nt + sc1, as the GEMMs' weight stream (work-group uniform)
-    const int kv_policy = (a.dbg & 128) ? 1 : ((a.dbg & 256) ? 2 : 0);
+    // cache policy of the K / V stream: a COMPILE-time constant (LADE_KV_AUX; bits 1 = sc0, 2 = nt, 16 = sc1) - variants are separate builds
     auto issue_tiles = [&](int stage, int ts, int tile) {
-        if ((NPC > 0 && tile - base >= sc1_from_q) || kv_policy == 1) issue_tiles_aux(stage, ts, tile, std::integral_constant<int, 16>{});
-        else if (kv_policy == 2) issue_tiles_aux(stage, ts, tile, std::integral_constant<int, 18>{});
-        else issue_tiles_aux(stage, ts, tile, std::integral_constant<int, 0>{});
+        if (NPC > 0 && tile - base >= sc1_from_q) issue_tiles_aux(stage, ts, tile, std::integral_constant<int, 16>{});
+        else issue_tiles_aux(stage, ts, tile, std::integral_constant<int, LADE_KV_AUX>{});
     };
     const int nt = (my_tiles + TPS - 1) / TPS;                                  // stages
     const int nt_issued = max(nt, NSTG);                                        // the first NSTG stages are always in flight

@@ -20,6 +20,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef LADE_G_NSTAGE_DEFAULT
 #define LADE_G_NSTAGE_DEFAULT 4
 #endif
+// cache-policy bits of the weight stream (1 = sc0, 2 = nt, 16 = sc1): a COMPILE-time constant - variants are separate builds (tools/build_variant.sh NAME
+// "-DLADE_W_AUX=18"): a run-time case in the DMA issue loop costs the step several per cent by itself
+#ifndef LADE_W_AUX
+#define LADE_W_AUX 2
+#endif
 constexpr int G_NSTAGE_CAP = 8;
 constexpr int G_LDS_MAX = 160 * 1024;
 constexpr int g_stages(int bn, int bm) {
@@ -297,15 +302,13 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
             unsigned char* dst = sbase + p_dst[i];
             // cache policy of the weight stream (bits: 1 = sc0, 2 = nt, 16 = sc1): NON-TEMPORAL (round 2) - every weight byte is read by exactly one
             // work-group, once per step, so keeping it in L2 / the Infinity Cache only evicts what is re-read (activation tiles, partials): 97.2 -> 92.0 us
-            // per 7B layer at 60 rows, decode step 4.65 -> 4.51 ms (LADE_DEBUG=gemm_dbg=16 turns it off).  nt + sc1 (round 6, gemm_dbg=256) wins 7-17 % on
-            // ISOLATED back-to-back launches and LOSES 4-7 % in the step (c2 4.20 vs 3.93 ms, c4 8.53 vs 8.15, every row count of the rows curve:
-            // profiles/r6_weight_cache_policy_*.txt) - one more case of isolated launches not ranking like the step.
-            if (p_w[i] && (g.dbg & 256))
+            // per 7B layer at 60 rows, decode step 4.65 -> 4.51 ms (LADE_DEBUG=gemm_dbg=16 turns it off).  nt + sc1 (round 6, -DLADE_W_AUX=18) wins 7-17 % on
+            // ISOLATED back-to-back launches and is neutral to +1 % in the step (c2 3.90 / 3.90 vs 3.84 / 3.89 ms, c4 7.95 / 7.95 vs 7.95 / 7.84 with one
+            // library per arm: profiles/r6_cache_policy_variants_ab.txt).  A first A/B through a RUN-TIME switch had read +7 %: the third case in this loop cost
+            // the step ~5 % by itself and fell on one arm - the policy is a compile-time constant now.
+            if (p_w[i] && nt_weights)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 18);
-            else if (p_w[i] && nt_weights)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 2);
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, LADE_W_AUX);
             else
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
