@@ -297,4 +297,5 @@ def test_pmc_traffic_falls_back_to_the_nearest_profiled_split_count():
     assert est5 == exact - per_split
     assert bench.pmc_traffic(cfg, 61, 2219, 6, 128) == (None, None)                   # another row count: nothing to go by
     gqa, srcg = bench.pmc_traffic(dict(heads=64, kv_heads=8, head_dim=128), 60, 2219, 4, 64)      # the GQA launch adopted in round 6
-    assert gqa == 20659200 and "ESTIMATE" not in srcg
+    alg = 2 * (2 * 8 * (2219 + 60) * 128 + 2 * 64 * 60 * 128)
+    assert gqa and 1.7 < gqa / alg < 2.0 and "ESTIMATE" not in srcg                   # 1.83 x algorithmic (2.25 x at the 128-row x 6-split launch of round 5)
