@@ -25,6 +25,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef LADE_W_AUX
 #define LADE_W_AUX 2
 #endif
+#ifndef LADE_A_AUX
+#define LADE_A_AUX 0          // the activation tile (and the weight stream when LADE_DEBUG=gemm_dbg=16 turns nt off)
+#endif
 constexpr int G_NSTAGE_CAP = 8;
 constexpr int G_LDS_MAX = 160 * 1024;
 constexpr int g_stages(int bn, int bm) {
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_skinny_kernel(GemmK g) {
                                                  (__attribute__((address_space(3))) void*)dst, 16, 0, LADE_W_AUX);
             else
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, LADE_A_AUX);
         }
     };
 
