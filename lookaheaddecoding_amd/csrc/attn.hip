@@ -33,6 +33,10 @@
 #ifndef LADE_KV_AUX
 #define LADE_KV_AUX 18
 #endif
+// the partial (or final) output rows stored write-through (sc1) instead of plain: a compile-time variant (tools/build_variant.sh NAME "-DLADE_PO_WT=1")
+#ifndef LADE_PO_WT
+#define LADE_PO_WT 0
+#endif
 
 namespace lade {
 
@@ -1076,7 +1080,12 @@ __global__ __launch_bounds__(64 * RG * KQ) void attn_fwd_kernel(AttnK a) {
         int hg2, t2;
         split_row(row0 + row, hg2, t2);
         const u32x4 v = *reinterpret_cast<const u32x4*>(stg_base + (size_t)(row >> 5) * stg_stride + (row & 31) * RS + c * 16);
-        *reinterpret_cast<u32x4*>(obase + (size_t)t2 * ostride + (size_t)(kvh * n_rep + hg2) * D + c * 8) = v;
+        uint16_t* dstp = obase + (size_t)t2 * ostride + (size_t)(kvh * n_rep + hg2) * D + c * 8;
+#if LADE_PO_WT
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dstp), "v"(v) : "memory");          // write-through: nothing dirty left for the boundary in front of the merge
+#else
+        *reinterpret_cast<u32x4*>(dstp) = v;
+#endif
     }
     dbg_stamp(a, 5);
 #ifdef LADE_ATTN_TIMELINE

@@ -225,11 +225,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmK& g, f32x16 (&acc)[MT][
             if (m0 + row < g.M && n0 + c * 4 < g.N) {
                 const float4 v = *reinterpret_cast<const float4*>(stg + row * RSF + c * 16);
                 float* dstp = outp + (size_t)(m0 + row) * g.N + n0 + c * 4;
-                if (g.dbg & 8) {                       // experiment: write-through partial stores (nothing left dirty in L2 at the kernel boundary)
+                // plain stores.  Round 6 measured the alternatives IN THE STEP, alternating, two boxes (profiles/r6_partial_store_policy_ab*.txt): write-through
+                // (sc1; LADE_DEBUG=gemm_dbg=8) c2 cold -0.8 % / -0.1 %, mid and hot regimes -0.6 ... -1.3 %, c4 0 ... +1 %: inside the noise taken together;
+                // non-temporal (gemm_dbg=64) equal in the step, plain decoding +2 %.  (The switch sits in the epilogue, outside the K loop.)
+                if (g.dbg & 8) {
                     const u32x4 vv = u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
                     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dstp), "v"(vv) : "memory");
                 }
-                else if (g.dbg & 64)                   // experiment: non-temporal partial stores (faster GEMM, slower consumer: DESIGN 4.6)
+                else if (g.dbg & 64)
                     __builtin_nontemporal_store(u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, reinterpret_cast<u32x4*>(dstp));
                 else
                     *reinterpret_cast<float4*>(dstp) = v;
